@@ -1,0 +1,120 @@
+"""ctypes front end of oracle/mppi_oracle.c (TEST INFRASTRUCTURE ONLY).
+
+The C file is the restatement; this module only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+TRIG_LIBM = 0
+TRIG_SPEC = 1
+
+
+class OracleParams(C.Structure):
+    _fields_ = [
+        ("K", C.c_int32), ("T", C.c_int32), ("G", C.c_int32), ("trig", C.c_int32),
+        ("res", C.c_float), ("x0", C.c_float), ("y0", C.c_float),
+        ("x_lo", C.c_float), ("x_hi", C.c_float), ("y_lo", C.c_float), ("y_hi", C.c_float),
+        ("dt", C.c_float), ("thr", C.c_float), ("lambda_", C.c_float),
+        ("sigma", C.c_float * 2), ("inv_var", C.c_float * 2),
+        ("u_min", C.c_float * 2), ("u_max", C.c_float * 2), ("goal", C.c_float * 2),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (make -C oracle)."""
+    src = os.path.join(_HERE, "mppi_oracle.c")
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        assert _lib.oracle_params_size() == C.sizeof(OracleParams)
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def make_params(K, T, G, res, goal, thr=0.3, lambda_=0.5, sigma=(0.5, 0.5), inv_var=None,
+                u_min=(0.0, -1.0), u_max=(1.0, 1.0), dt=0.1, x_limits=None, y_limits=None,
+                trig=TRIG_SPEC) -> OracleParams:
+    """Geometry defaults follow grid_map.py:42-50 (limits [0, G*res], origin = lower limit)."""
+    if x_limits is None:
+        c = G * res / 2
+        x_limits = (c - G / 2 * res, c + G / 2 * res)
+    if y_limits is None:
+        y_limits = x_limits
+    if inv_var is None:
+        s32 = np.asarray(sigma, np.float32)
+        inv_var = (np.float32(1) / (s32 * s32)).tolist()
+    p = OracleParams()
+    p.K, p.T, p.G, p.trig = int(K), int(T), int(G), int(trig)
+    p.res = res
+    p.x0, p.y0 = x_limits[0], y_limits[0]
+    p.x_lo, p.x_hi = x_limits
+    p.y_lo, p.y_hi = y_limits
+    p.dt, p.thr, p.lambda_ = dt, thr, lambda_
+    for i in range(2):
+        p.sigma[i] = sigma[i]
+        p.inv_var[i] = inv_var[i]
+        p.u_min[i] = u_min[i]
+        p.u_max[i] = u_max[i]
+        p.goal[i] = float(goal[i])
+    return p
+
+
+def solve(p: OracleParams, R, state, mean, eps):
+    """One MPPI solve. Returns dict(U, X, cost, w, Ustar, Xstar) of float32 arrays."""
+    K, T, G = p.K, p.T, p.G
+    R = _f32(R, (G, G)); state = _f32(state, (3,)); mean = _f32(mean, (T, 2)); eps = _f32(eps, (K, T, 2))
+    out = dict(U=np.empty((K, T, 2), np.float32), X=np.empty((K, T + 1, 3), np.float32),
+               cost=np.empty(K, np.float32), w=np.empty(K, np.float32),
+               Ustar=np.empty((T, 2), np.float32), Xstar=np.empty((T + 1, 3), np.float32))
+    lib().oracle_solve(C.byref(p), _fp(R), _fp(state), _fp(mean), _fp(eps), _fp(out["U"]),
+                       _fp(out["X"]), _fp(out["cost"]), _fp(out["w"]), _fp(out["Ustar"]),
+                       _fp(out["Xstar"]))
+    return out
+
+
+def rollout(p: OracleParams, R, state, u):
+    R = _f32(R, (p.G, p.G)); state = _f32(state, (3,)); u = _f32(u, (p.T, 2))
+    X = np.empty((p.T + 1, 3), np.float32)
+    lib().oracle_rollout(C.byref(p), _fp(R), _fp(state), _fp(u), _fp(X))
+    return X
+
+
+def env_step(p: OracleParams, trav, state, u):
+    state = _f32(state, (3,)); u = _f32(u, (2,))
+    nxt = np.empty(3, np.float32)
+    lib().oracle_env_step(C.byref(p), C.c_float(trav), _fp(state), _fp(u), _fp(nxt))
+    return nxt
+
+
+def sincos(x, trig=TRIG_SPEC):
+    x = _f32(x).ravel()
+    s = np.empty_like(x); c = np.empty_like(x)
+    lib().oracle_sincos(C.c_int32(trig), C.c_int64(x.size), _fp(x), _fp(s), _fp(c))
+    return s, c
