@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""MPPI solve-steps/sec on MI355X (BASELINE.json metric) -- one JSON line on stdout.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[1] -- a single 256x256 map, K=1024 rollouts,
+T=50 steps, one planning instance per GPU.  A "step" is one complete MPPI solve (noise sampling,
+K x T rollout with per-step map lookups, stage/terminal/control costs, softmin weights, weighted
+control reduction, optimal-sequence rollout, warm-start update) -- the work of the reference's
+MPPI.forward (mppi.py:130-219).  Successive steps are warm-started from the previous U*, so they
+form a dependent chain exactly like the reference's closed loop; the planner state is held fixed
+(open-loop variant).  Inputs (map, goal, state, mean) are resident in HBM before
+the timed region.  With N > 1 every rank plans its own map seed (instance sharding, no data-path
+collective); RCCL is used only to agree on the slowest rank's time.
+
+Extra objects on the line:
+  roofline      dominant kernel (rollout) against the HBM roofline, algorithmic bytes per launch
+                over the kernel's mean duration measured with HIP events on the launch stream
+  cpu_baseline  the PyTorch-CPU port of the reference (oracle/torch_port.py) timed on this host
+  batched       64 instances per launch (config 4's per-node batch on one GPU): the regime where
+                the HBM roofline is meaningful
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from benchnav_amd import NativeMPPI, _capi, synth  # noqa: E402
+
+G, K, T, RES = 256, 1024, 50, 0.5
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--noise", choices=["philox", "injected"], default="philox",
+                    help="philox: sampled inside the rollout kernel (timed); injected: pre-generated eps resident in HBM")
+    ap.add_argument("--batched-instances", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_planner(inst, dev, B=1, profile=False, shared_map=True):
+    pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, shared_map=shared_map,
+                    device_id=dev, profile=profile, stream=torch.cuda.current_stream().cuda_stream)
+    pl.set_map(inst.risk.numpy())
+    pl.set_goal(inst.goal.numpy())
+    return pl
+
+
+def timed_solves(pl, state_dev, eps_ring, kind, steps, sync):
+    """Enqueue `steps` dependent solves; returns wall seconds between the two syncs."""
+    sync()
+    t0 = time.perf_counter()
+    if eps_ring is None:
+        for _ in range(steps):
+            pl.solve_async_device(state_dev.data_ptr())
+    else:
+        n = len(eps_ring)
+        for i in range(steps):
+            pl.solve_async_device(state_dev.data_ptr(), eps_ring[i % n].data_ptr(), kind)
+    sync()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(inst, seconds):
+    """The reference's CPU path, as ported in oracle/torch_port.py, on this box's host cores."""
+    from oracle import torch_port as TP
+    pb = TP.Problem(risk=inst.risk, goal=inst.goal, grid_size=G, resolution=RES, x_limits=(0.0, G * RES),
+                    y_limits=(0.0, G * RES), sigmas=torch.tensor([0.5, 0.5]), lambda_=0.5, stuck_threshold=0.3,
+                    u_min=torch.tensor([0.0, -1.0]), u_max=torch.tensor([1.0, 1.0]))
+    torch.manual_seed(42)
+    mean = torch.zeros(T, 2)
+    for _ in range(3):
+        mean = TP.solve(pb, inst.start, mean, K=K)["Ustar"]
+    n, t0 = 0, time.perf_counter()
+    while True:
+        mean = TP.solve(pb, inst.start, mean, K=K)["Ustar"]      # warm-started chain, noise drawn per solve
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 2000:
+            break
+    out = {"value": n / el, "unit": "solves/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} warm-started solves of the same workload (K={K}, T={T}, {G}x{G} map) in {el:.1f} s, "
+                     f"PyTorch-CPU port of mppi.py:130-219 (oracle/torch_port.py), torch {torch.__version__}, "
+                     f"{os.cpu_count()} host cpus"}
+    # the scalar C oracle on one core, for scale (a stronger CPU implementation than the reference's)
+    try:
+        from oracle import oracle as O
+        p = O.make_params(K, T, G, RES, inst.goal.numpy(), trig=O.TRIG_SPEC)
+        eps = np.random.default_rng(0).standard_normal((K, T, 2)).astype(np.float32)
+        R, st, mn = inst.risk.numpy(), inst.start.numpy(), np.zeros((T, 2), np.float32)
+        O.solve(p, R, st, mn, eps)
+        m, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < min(3.0, seconds):
+            O.solve(p, R, st, mn, eps)
+            m += 1
+        out["c_oracle_1core_solves_per_s"] = m / (time.perf_counter() - t1)
+    except Exception as e:  # the C oracle is optional for the baseline leg
+        out["c_oracle_error"] = str(e)
+    return out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the MPPI planner has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    inst = synth.make_instance(G, seed=rank, resolution=RES)       # independent map seed per rank
+    state_dev = inst.start.cuda()
+    if a.noise == "injected":
+        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        eps_ring = [torch.randn(T, 2, K, device="cuda", generator=gen) for _ in range(8)]
+        kind = _capi.BN_NOISE_DEVICE_T2K
+    else:
+        eps_ring, kind = None, _capi.BN_NOISE_PHILOX
+
+    # ---- headline: dependent solves of one instance per GPU -------------------------------------
+    pl = make_planner(inst, local)
+    timed_solves(pl, state_dev, eps_ring, kind, a.warmup, sync)
+    elapsed = timed_solves(pl, state_dev, eps_ring, kind, a.steps, sync)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                # the only collective: 8 bytes
+        elapsed = float(tmax.item())
+    value = world * a.steps / elapsed
+    alg_bytes = pl.algorithmic_bytes(injected_noise=(a.noise == "injected"))
+    pl.close()
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events around every launch, same K steps -------
+        plp = make_planner(inst, local, profile=True)
+        timed_solves(plp, state_dev, eps_ring, kind, min(a.warmup, 50), torch.cuda.synchronize)
+        plp.kernel_ms()
+        el_prof = timed_solves(plp, state_dev, eps_ring, kind, a.steps, torch.cuda.synchronize)
+        r_ms, f_ms, n_prof = plp.kernel_ms()
+        plp.close()
+        achieved = alg_bytes / (r_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, see profiles/README.md
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"rollout_{a.noise}_B1")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPPI solve-steps/sec (K=1024,T=50,256x256 map)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: single 256x256 map, K=1024, T=50, one instance per GPU, "
+                                   "dependent warm-started solves, fixed state",
+                       "grid": G, "num_samples": K, "horizon": T, "resolution": RES, "instances_per_gpu": 1,
+                       "noise": "philox in-kernel (sampling inside the timed region)" if a.noise == "philox"
+                                else "injected eps (T,2,K) resident in HBM",
+                       "parallelism": f"instance sharding x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "bn::rollout_kernel", "kernel_ms": r_ms, "finish_kernel_ms": f_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_prof,
+                         "ms_per_step_with_events": el_prof / a.steps * 1e3,
+                         "note": "single-instance solve is a 2xT-step dependent chain: latency-bound, see DESIGN.md"},
+        }
+        # ---- batched: 64 instances per launch on this GPU (HBM-relevant regime) -------------------
+        if not a.no_batched and world == 1:
+            B = a.batched_instances
+            insts = [synth.make_instance(G, seed=s, resolution=RES, jitter=True) for s in range(B)]
+            plb = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=local,
+                             profile=True, stream=torch.cuda.current_stream().cuda_stream)
+            for b, it in enumerate(insts):
+                plb.set_map(it.risk.numpy(), b)
+                plb.set_goal(it.goal.numpy(), b)
+            states = torch.stack([it.start for it in insts]).cuda()
+            if a.noise == "injected":
+                ring = [torch.randn(B, T, 2, K, device="cuda") for _ in range(2)]
+            else:
+                ring = None
+            nb = max(20, a.steps // 20)
+            timed_solves(plb, states, ring, kind, 10, torch.cuda.synchronize)
+            plb.kernel_ms()
+            elb = timed_solves(plb, states, ring, kind, nb, torch.cuda.synchronize)
+            rb, fb, _ = plb.kernel_ms()
+            bytes_b = plb.algorithmic_bytes(injected_noise=(a.noise == "injected")) * B
+            plb.close()
+            out["batched"] = {"instances_per_launch": B, "value": B * nb / elb, "unit": "solves/s",
+                              "ms_per_launch": elb / nb * 1e3,
+                              "roofline": {"bound": "hbm", "achieved": bytes_b / (rb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": bytes_b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "kernel_ms": rb, "finish_kernel_ms": fb,
+                                           "algorithmic_bytes_per_launch": bytes_b}}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

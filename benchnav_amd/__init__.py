@@ -1,0 +1,13 @@
+"""benchnav_amd -- MI355X-native MPPI local planner for BenchNav (hot path only).
+
+    from benchnav_amd import MPPI          # drop-in for src/planners/local_planners/mppi.py:MPPI
+    from benchnav_amd import NativeMPPI    # numpy-level wrapper of the C ABI, B instances per call
+"""
+from .native import NativeMPPI  # noqa: F401
+
+
+def __getattr__(name):
+    if name == "MPPI":          # torch is imported only when the torch-facing class is used
+        from .mppi import MPPI
+        return MPPI
+    raise AttributeError(name)

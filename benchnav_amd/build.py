@@ -1,0 +1,49 @@
+"""In-tree build of the gfx950 library (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_PKG, "csrc")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libbenchnav_mppi.so")
+SOURCES = ["mppi_kernels.hip", "mppi_capi.cpp"]
+HEADERS = ["mppi_kernels.h", "bn_device_math.h", os.path.join("..", "..", "include", "benchnav_mppi.h")]
+
+# -ffp-contract=off: the arithmetic spec fixes where FMAs are (explicit __builtin_fmaf only).
+# Division and sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MPPI planner needs the ROCm toolchain to build")
+    return exe
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    """Compile csrc/*.hip|cpp into lib/libbenchnav_mppi.so for gfx950."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc(), *HIPCC_FLAGS, *extra_flags, "-x", "hip", *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

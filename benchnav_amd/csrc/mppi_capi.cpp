@@ -1,0 +1,540 @@
+// mppi_capi.cpp -- host side of the C ABI declared in include/benchnav_mppi.h.
+//
+// Owns the device buffers of one planner handle and enqueues the two kernels of
+// a solve (mppi_kernels.hip) on the handle's HIP stream.  No torch types, no CPU
+// fallback: creation fails without a gfx950 device.
+#include "../../include/benchnav_mppi.h"
+#include "mppi_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define BN_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(BN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+bool is_pow2_float(float v)
+{
+    int ex;
+    return v > 0.0f && std::isfinite(v) && std::frexp(v, &ex) == 0.5f;
+}
+
+}  // namespace
+
+struct bn_mppi {
+    bn_mppi_config cfg{};
+    bn::SolveParams p{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_maps = 1;
+    uint64_t solves = 0;
+    bool map_set = false, goal_set = false;
+    // device buffers
+    float *d_map = nullptr, *d_state = nullptr, *d_goal = nullptr, *d_mean = nullptr, *d_eps = nullptr;
+    float *d_X = nullptr, *d_U = nullptr, *d_cost = nullptr, *d_part = nullptr, *d_w = nullptr;
+    float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
+    int *d_idx = nullptr;
+    unsigned long long *d_counter = nullptr;
+    size_t scratch_bytes = 0, eps_bytes = 0, idx_count = 0;
+    float *h_pinned = nullptr;   // pinned staging for (B,3) states
+    // profiling
+    std::vector<hipEvent_t> ev;  // 3 events per profiled solve: start, after rollout, after finish
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int bind_device(const bn_mppi *h) { return hipSetDevice(h->cfg.device_id) == hipSuccess ? BN_OK : BN_ERR_HIP; }
+
+size_t buffer_bytes(const bn_mppi *h, bn_buffer_id id)
+{
+    const size_t B = h->p.B, K = h->p.K, T = h->p.T, G = h->p.G;
+    switch (id) {
+    case BN_BUF_STATES: return B * (T + 1) * 3 * K * 4;
+    case BN_BUF_WEIGHTS: return B * K * 4;
+    case BN_BUF_COSTS: return B * K * 4;
+    case BN_BUF_CONTROLS: return h->d_U ? B * T * 2 * K * 4 : 0;
+    case BN_BUF_USTAR: return B * T * 2 * 4;
+    case BN_BUF_XSTAR: return B * (T + 1) * 3 * 4;
+    case BN_BUF_MEAN: return B * T * 2 * 4;
+    case BN_BUF_MAP: return (size_t)h->n_maps * G * G * 4;
+    case BN_BUF_GOAL: return B * 2 * 4;
+    default: return 0;
+    }
+}
+
+int ensure_scratch(bn_mppi *h, size_t bytes)
+{
+    if (bytes <= h->scratch_bytes) return BN_OK;
+    if (h->d_scratch) BN_HIP(hipFree(h->d_scratch));
+    h->d_scratch = nullptr;
+    h->scratch_bytes = 0;
+    BN_HIP(hipMalloc(&h->d_scratch, bytes));
+    h->scratch_bytes = bytes;
+    return BN_OK;
+}
+
+int check_instance(const bn_mppi *h, int32_t instance, bool allow_all)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (instance == -1 && allow_all) return BN_OK;
+    if (instance < 0 || instance >= h->p.B)
+        return fail(BN_ERR_INVALID, "instance %d out of range [0,%d)", instance, h->p.B);
+    return BN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bn_mppi_config_init(bn_mppi_config *c)
+{
+    std::memset(c, 0, sizeof *c);
+    c->struct_size = sizeof *c;
+    c->horizon = 50;
+    c->num_samples = 1024;
+    c->num_instances = 1;
+    c->grid_size = 64;
+    c->resolution = 0.5f;
+    c->x_limits[0] = c->y_limits[0] = 0.0f;
+    c->x_limits[1] = c->y_limits[1] = 32.0f;
+    c->sigma[0] = c->sigma[1] = 0.5f;
+    c->inv_var[0] = c->inv_var[1] = 4.0f;
+    c->lambda_ = 0.5f;
+    c->u_min[0] = 0.0f; c->u_min[1] = -1.0f;
+    c->u_max[0] = 1.0f; c->u_max[1] = 1.0f;
+    c->dt = 0.1f;
+    c->stuck_threshold = 0.3f;
+    c->seed = 42;
+}
+
+int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
+{
+    if (!cfg || !out) return fail(BN_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(bn_mppi_config))
+        return fail(BN_ERR_INVALID, "bn_mppi_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                    sizeof(bn_mppi_config));
+    if (cfg->horizon < 1 || cfg->num_samples < 1 || cfg->num_instances < 1 || cfg->grid_size < 1)
+        return fail(BN_ERR_INVALID, "horizon, num_samples, num_instances and grid_size must be >= 1");
+    if (cfg->num_instances > 65535) return fail(BN_ERR_INVALID, "num_instances must be <= 65535");
+    if (!(cfg->resolution > 0.0f) || !(cfg->lambda_ > 0.0f) || !(cfg->dt > 0.0f))
+        return fail(BN_ERR_INVALID, "resolution, lambda_ and dt must be positive");
+    for (int d = 0; d < 2; ++d)
+        if (!(cfg->u_min[d] <= cfg->u_max[d]) || !(cfg->sigma[d] >= 0.0f))
+            return fail(BN_ERR_INVALID, "need u_min <= u_max and sigma >= 0");
+    // The kernels share one gather between stage cost t and transit t+1; that needs the upper clamp
+    // to land in the last cell, as it does for every reference GridMap (grid_map.py:42-50).
+    const float span_x = (cfg->x_limits[1] - cfg->x_limits[0]) / cfg->resolution;
+    const float span_y = (cfg->y_limits[1] - cfg->y_limits[0]) / cfg->resolution;
+    if (!(span_x >= (float)(cfg->grid_size - 1)) || !(span_y >= (float)(cfg->grid_size - 1)))
+        return fail(BN_ERR_INVALID, "x/y_limits must span at least grid_size-1 cells of `resolution`");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(BN_ERR_NO_DEVICE, "no HIP device visible: the MPPI planner has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(BN_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    BN_HIP(hipSetDevice(cfg->device_id));
+    hipDeviceProp_t prop;
+    BN_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BN_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", cfg->device_id,
+                    prop.gcnArchName);
+
+    bn_mppi *h = new bn_mppi();
+    h->cfg = *cfg;
+    bn::SolveParams &p = h->p;
+    p.K = cfg->num_samples; p.T = cfg->horizon; p.G = cfg->grid_size; p.B = cfg->num_instances;
+    p.nblk = (p.K + bn::kRolloutsPerBlock - 1) / bn::kRolloutsPerBlock;
+    p.res = cfg->resolution; p.inv_res = 1.0f / cfg->resolution;
+    p.pow2 = is_pow2_float(cfg->resolution) ? 1 : 0;
+    p.x0 = cfg->x_limits[0]; p.y0 = cfg->y_limits[0];
+    p.x_hi = cfg->x_limits[1]; p.y_hi = cfg->y_limits[1];
+    p.dt = cfg->dt; p.thr = cfg->stuck_threshold; p.lambda_ = cfg->lambda_;
+    p.sigma0 = cfg->sigma[0]; p.sigma1 = cfg->sigma[1];
+    p.iv0 = cfg->inv_var[0]; p.iv1 = cfg->inv_var[1];
+    p.umin0 = cfg->u_min[0]; p.umax0 = cfg->u_max[0];
+    p.umin1 = cfg->u_min[1]; p.umax1 = cfg->u_max[1];
+    p.seed = cfg->seed;
+    p.store_u = (cfg->flags & BN_FLAG_STORE_CONTROLS) ? 1 : 0;
+    h->n_maps = (cfg->flags & BN_FLAG_SHARED_MAP) ? 1 : p.B;
+    p.map_stride = (h->n_maps == 1) ? 0 : p.G * p.G;
+
+    // Reachable window: |dx| per step <= trav*|v|*dt <= vmax*dt (robot_model.py:82,86-87).
+    const double vmax = std::max(std::fabs((double)cfg->u_min[0]), std::fabs((double)cfg->u_max[0]));
+    const double reach_cells = std::ceil((double)p.T * vmax * (double)cfg->dt / (double)cfg->resolution) + 1.0;
+    p.reach = (int)std::min(reach_cells, (double)p.G);
+    p.WN = std::min(p.G, 2 * p.reach + 1);
+    const size_t lds_budget = 160 * 1024;
+    if ((cfg->flags & BN_FLAG_NO_LDS_WINDOW) || bn::rollout_lds_bytes(p) > lds_budget) p.WN = 0;
+    if (bn::rollout_lds_bytes(p) > lds_budget) {
+        delete h;
+        return fail(BN_ERR_INVALID, "horizon %d needs %zu B of LDS for the control tile (> 160 KiB)", p.T,
+                    bn::rollout_lds_bytes(p));
+    }
+
+    int rc = BN_OK;
+    auto alloc = [&](auto **ptr, size_t bytes) {
+        if (rc != BN_OK) return;
+        hipError_t e = hipMalloc((void **)ptr, bytes);
+        if (e == hipSuccess) e = hipMemset(*ptr, 0, bytes);
+        if (e != hipSuccess) rc = fail(BN_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    };
+    const size_t B = p.B, K = p.K, T = p.T, G = p.G;
+    alloc(&h->d_map, (size_t)h->n_maps * G * G * 4);
+    alloc(&h->d_state, B * 3 * 4);
+    alloc(&h->d_goal, B * 2 * 4);
+    alloc(&h->d_mean, B * T * 2 * 4);
+    alloc(&h->d_X, B * (T + 1) * 3 * K * 4);
+    if (p.store_u) alloc(&h->d_U, B * T * 2 * K * 4);
+    alloc(&h->d_cost, B * K * 4);
+    alloc(&h->d_part, B * (size_t)p.nblk * (2 + 2 * T) * 4);
+    alloc(&h->d_w, B * K * 4);
+    alloc(&h->d_ustar, B * T * 2 * 4);
+    alloc(&h->d_xstar, B * (T + 1) * 3 * 4);
+    alloc(&h->d_stats, B * 2 * 4);
+    alloc(&h->d_counter, sizeof(unsigned long long));
+    if (rc == BN_OK && hipHostMalloc((void **)&h->h_pinned, B * 3 * 4, hipHostMallocDefault) != hipSuccess)
+        rc = fail(BN_ERR_HIP, "hipHostMalloc failed");
+    if (rc == BN_OK) {
+        if (!(cfg->flags & BN_FLAG_PRIVATE_STREAM)) {
+            h->stream = (hipStream_t)cfg->stream;          // may be the null stream
+        } else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess) {
+            h->own_stream = true;
+        } else {
+            rc = fail(BN_ERR_HIP, "hipStreamCreate failed");
+        }
+    }
+    if (rc != BN_OK) {
+        bn_mppi_destroy(h);
+        return rc;
+    }
+    p.map = h->d_map; p.state = h->d_state; p.goal = h->d_goal; p.mean = h->d_mean; p.eps = nullptr;
+    p.X = h->d_X; p.U = h->d_U; p.cost = h->d_cost; p.part = h->d_part; p.w = h->d_w;
+    p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats; p.counter = h->d_counter;
+    BN_HIP(hipDeviceSynchronize());
+    *out = h;
+    return BN_OK;
+}
+
+void bn_mppi_destroy(bn_mppi_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost, h->d_part,
+                    h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_counter};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_kind where)
+{
+    if (int rc = check_instance(h, instance, true)) return rc;
+    if (!risk) return fail(BN_ERR_INVALID, "risk is null");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    const size_t bytes = (size_t)h->p.G * h->p.G * 4;
+    const hipMemcpyKind kind = where == BN_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const int lo = instance < 0 ? 0 : std::min(instance, h->n_maps - 1);
+    const int hi = instance < 0 ? h->n_maps : lo + 1;
+    BN_HIP(hipStreamSynchronize(h->stream));
+    for (int m = lo; m < hi; ++m) BN_HIP(hipMemcpy(h->d_map + (size_t)m * h->p.G * h->p.G, risk, bytes, kind));
+    h->map_set = true;
+    return BN_OK;
+}
+
+int bn_mppi_set_goal(bn_mppi_t *h, int32_t instance, const float goal_host[2])
+{
+    if (int rc = check_instance(h, instance, true)) return rc;
+    if (!goal_host) return fail(BN_ERR_INVALID, "goal is null");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(hipStreamSynchronize(h->stream));
+    const int lo = instance < 0 ? 0 : instance, hi = instance < 0 ? h->p.B : instance + 1;
+    for (int b = lo; b < hi; ++b) BN_HIP(hipMemcpy(h->d_goal + b * 2, goal_host, 8, hipMemcpyHostToDevice));
+    h->goal_set = true;
+    return BN_OK;
+}
+
+int bn_mppi_set_mean(bn_mppi_t *h, int32_t instance, const float *mean_host)
+{
+    if (int rc = check_instance(h, instance, true)) return rc;
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->p.T * 2;
+    const int lo = instance < 0 ? 0 : instance, hi = instance < 0 ? h->p.B : instance + 1;
+    for (int b = lo; b < hi; ++b) {
+        if (mean_host) BN_HIP(hipMemcpy(h->d_mean + b * n, mean_host, n * 4, hipMemcpyHostToDevice));
+        else BN_HIP(hipMemset(h->d_mean + b * n, 0, n * 4));
+    }
+    return BN_OK;
+}
+
+int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (!mean_host) return fail(BN_ERR_INVALID, "null output");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->p.T * 2;
+    BN_HIP(hipMemcpy(mean_host, h->d_mean + instance * n, n * 4, hipMemcpyDeviceToHost));
+    return BN_OK;
+}
+
+int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
+                        bn_noise_kind noise)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!states) return fail(BN_ERR_INVALID, "states is null");
+    if (!h->map_set || !h->goal_set) return fail(BN_ERR_STATE, "set_map and set_goal must precede solve");
+    if ((noise == BN_NOISE_PHILOX) != (eps == nullptr))
+        return fail(BN_ERR_INVALID, "eps must be NULL exactly when noise == BN_NOISE_PHILOX");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+
+    bn::SolveParams p = h->p;
+    const size_t B = p.B, K = p.K, T = p.T;
+    if (states_where == BN_MEM_DEVICE) {
+        p.state = states;
+    } else {
+        // the pinned block may still feed a previous copy: wait for the stream before reusing it
+        if (h->solves) BN_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(h->h_pinned, states, B * 3 * 4);
+        BN_HIP(hipMemcpyAsync(h->d_state, h->h_pinned, B * 3 * 4, hipMemcpyHostToDevice, h->stream));
+        p.state = h->d_state;
+    }
+    bn::EpsMode mode = bn::kEpsPhilox;
+    switch (noise) {
+    case BN_NOISE_PHILOX: break;
+    case BN_NOISE_HOST_KT2: {
+        const size_t bytes = B * K * T * 2 * 4;
+        if (bytes > h->eps_bytes) {
+            if (h->d_eps) BN_HIP(hipFree(h->d_eps));
+            h->d_eps = nullptr; h->eps_bytes = 0;
+            BN_HIP(hipMalloc((void **)&h->d_eps, bytes));
+            h->eps_bytes = bytes;
+        }
+        BN_HIP(hipMemcpyAsync(h->d_eps, eps, bytes, hipMemcpyHostToDevice, h->stream));
+        p.eps = h->d_eps;
+        mode = bn::kEpsKT2;
+        break;
+    }
+    case BN_NOISE_DEVICE_KT2: p.eps = eps; mode = bn::kEpsKT2; break;
+    case BN_NOISE_DEVICE_T2K: p.eps = eps; mode = bn::kEpsT2K; break;
+    default: return fail(BN_ERR_INVALID, "unknown noise kind %d", (int)noise);
+    }
+
+    const bool prof = (h->cfg.flags & BN_FLAG_PROFILE) != 0;
+    hipEvent_t *ev = nullptr;
+    if (prof) {
+        if (h->ev_used + 3 > h->ev.size()) {
+            for (int i = 0; i < 3; ++i) {
+                hipEvent_t e;
+                BN_HIP(hipEventCreate(&e));
+                h->ev.push_back(e);
+            }
+        }
+        ev = &h->ev[h->ev_used];
+        h->ev_used += 3;
+        BN_HIP(hipEventRecord(ev[0], h->stream));
+    }
+    BN_HIP(bn::launch_rollout(p, mode, h->stream));
+    if (prof) BN_HIP(hipEventRecord(ev[1], h->stream));
+    BN_HIP(bn::launch_finish(p, h->stream));
+    if (prof) BN_HIP(hipEventRecord(ev[2], h->stream));
+    h->solves += 1;
+    return BN_OK;
+}
+
+int bn_mppi_sync(bn_mppi_t *h)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(hipStreamSynchronize(h->stream));
+    return BN_OK;
+}
+
+int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
+                  bn_noise_kind noise, float *ustar_host, float *xstar_host)
+{
+    if (int rc = bn_mppi_solve_async(h, states, states_where, eps, noise)) return rc;
+    const size_t B = h->p.B, T = h->p.T;
+    if (ustar_host) BN_HIP(hipMemcpyAsync(ustar_host, h->d_ustar, B * T * 2 * 4, hipMemcpyDeviceToHost, h->stream));
+    if (xstar_host)
+        BN_HIP(hipMemcpyAsync(xstar_host, h->d_xstar, B * (T + 1) * 3 * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    return BN_OK;
+}
+
+static int copy_out(bn_mppi_t *h, int32_t instance, const float *dev, size_t per_instance, float *out_host)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (!out_host) return fail(BN_ERR_INVALID, "null output");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(hipStreamSynchronize(h->stream));
+    BN_HIP(hipMemcpy(out_host, dev + (size_t)instance * per_instance, per_instance * 4, hipMemcpyDeviceToHost));
+    return BN_OK;
+}
+
+int bn_mppi_get_weights(bn_mppi_t *h, int32_t instance, float *out_host)
+{
+    return h ? copy_out(h, instance, h->d_w, h->p.K, out_host) : fail(BN_ERR_INVALID, "null handle");
+}
+
+int bn_mppi_get_costs(bn_mppi_t *h, int32_t instance, float *out_host)
+{
+    return h ? copy_out(h, instance, h->d_cost, h->p.K, out_host) : fail(BN_ERR_INVALID, "null handle");
+}
+
+int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (!out_host) return fail(BN_ERR_INVALID, "null output");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    const size_t K = h->p.K, T1 = h->p.T + 1, n = K * T1 * 3;
+    if (int rc = ensure_scratch(h, n * 4)) return rc;
+    BN_HIP(bn::launch_states_to_reference(h->d_X + (size_t)instance * n, h->d_scratch, (int)K, (int)T1, h->stream));
+    BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    return BN_OK;
+}
+
+int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (!out_host) return fail(BN_ERR_INVALID, "null output");
+    if (!h->d_U) return fail(BN_ERR_STATE, "controls are only stored with BN_FLAG_STORE_CONTROLS");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    const size_t K = h->p.K, T = h->p.T, n = K * T * 2;
+    if (int rc = ensure_scratch(h, n * 4)) return rc;
+    BN_HIP(bn::launch_controls_to_reference(h->d_U + (size_t)instance * n, h->d_scratch, (int)K, (int)T, h->stream));
+    BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    return BN_OK;
+}
+
+int bn_mppi_get_philox_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_index, float *out_host)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (!out_host) return fail(BN_ERR_INVALID, "null output");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    const size_t n = (size_t)h->p.K * h->p.T * 2;
+    if (int rc = ensure_scratch(h, n * 4)) return rc;
+    BN_HIP(bn::launch_philox_noise(h->d_scratch, h->p.seed, solve_index, instance, h->p.K, h->p.T, h->stream));
+    BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    return BN_OK;
+}
+
+int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *states_host, float *weights_host)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (n < 0 || n > h->p.K) return fail(BN_ERR_INVALID, "n=%d must satisfy 0 <= n <= K=%d", n, h->p.K);  // mppi.py:229
+    if (n == 0) return BN_OK;
+    if (!states_host || !weights_host) return fail(BN_ERR_INVALID, "null output");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    const size_t K = h->p.K, T1 = h->p.T + 1;
+    std::vector<float> w(K);
+    BN_HIP(hipStreamSynchronize(h->stream));
+    BN_HIP(hipMemcpy(w.data(), h->d_w + (size_t)instance * K, K * 4, hipMemcpyDeviceToHost));
+    std::vector<int> idx(K);
+    std::iota(idx.begin(), idx.end(), 0);
+    // topk + descending sort (mppi.py:232-238); ties resolved by the lower rollout index
+    std::partial_sort(idx.begin(), idx.begin() + n, idx.end(),
+                      [&](int a, int b) { return w[a] > w[b] || (w[a] == w[b] && a < b); });
+    if ((size_t)n > h->idx_count) {
+        if (h->d_idx) BN_HIP(hipFree(h->d_idx));
+        h->d_idx = nullptr; h->idx_count = 0;
+        BN_HIP(hipMalloc((void **)&h->d_idx, (size_t)n * sizeof(int)));
+        h->idx_count = n;
+    }
+    if (int rc = ensure_scratch(h, (size_t)n * T1 * 3 * 4)) return rc;
+    BN_HIP(hipMemcpyAsync(h->d_idx, idx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    BN_HIP(bn::launch_gather_states(h->d_X + (size_t)instance * K * T1 * 3, h->d_idx, h->d_scratch, n, (int)K,
+                                    (int)T1, h->stream));
+    BN_HIP(hipMemcpyAsync(states_host, h->d_scratch, (size_t)n * T1 * 3 * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) weights_host[i] = w[idx[i]];
+    return BN_OK;
+}
+
+int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size_t *bytes)
+{
+    if (!h || !device_ptr) return fail(BN_ERR_INVALID, "null argument");
+    void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal};
+    if ((int)id < 0 || id >= BN_BUF_COUNT_) return fail(BN_ERR_INVALID, "unknown buffer id %d", (int)id);
+    *device_ptr = ptrs[id];
+    if (bytes) *bytes = buffer_bytes(h, id);
+    if (!ptrs[id]) return fail(BN_ERR_STATE, "buffer %d is not allocated in this configuration", (int)id);
+    return BN_OK;
+}
+
+uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves : 0; }
+
+int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t *n_solves)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!(h->cfg.flags & BN_FLAG_PROFILE)) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_PROFILE");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(hipStreamSynchronize(h->stream));
+    double r = 0.0, f = 0.0;
+    const size_t n = h->ev_used / 3;
+    for (size_t i = 0; i < n; ++i) {
+        float a = 0.0f, b = 0.0f;
+        BN_HIP(hipEventElapsedTime(&a, h->ev[3 * i], h->ev[3 * i + 1]));
+        BN_HIP(hipEventElapsedTime(&b, h->ev[3 * i + 1], h->ev[3 * i + 2]));
+        r += a; f += b;
+    }
+    if (rollout_ms) *rollout_ms = n ? (float)(r / n) : 0.0f;
+    if (finish_ms) *finish_ms = n ? (float)(f / n) : 0.0f;
+    if (n_solves) *n_solves = (int32_t)n;
+    h->ev_used = 0;
+    return BN_OK;
+}
+
+int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise)
+{
+    if (!h) return 0;
+    const int64_t K = h->p.K, T = h->p.T, G = h->p.G;
+    int64_t bytes = 4 * G * G            // risk map read once
+                    + (8 * T + 12)       // mean, state
+                    + 12 * K * (T + 1)   // _state_seq_batch write
+                    + 4 * K              // weights write
+                    + 8 * T + 12 * (T + 1);   // U*, X* write
+    if (noise != BN_NOISE_PHILOX) bytes += 8 * K * T;   // injected noise read
+    if (h->d_U) bytes += 8 * K * T;                     // _perturbed_action_seqs write
+    return bytes;
+}
+
+const char *bn_last_error(void) { return g_last_error.c_str(); }
+int bn_mppi_abi_version(void) { return BN_MPPI_ABI_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// mppi_kernels.h -- launch interface between the C ABI (mppi_capi.cpp) and the
+// gfx950 kernels (mppi_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bn {
+
+constexpr int kRolloutsPerBlock = 64;   // one wavefront = 64 rollouts, lane = rollout
+constexpr int kUPad = 65;               // LDS row pitch of the control tile (bank-conflict-free both ways)
+constexpr int kFinishThreads = 256;
+
+enum EpsMode : int { kEpsPhilox = 0, kEpsKT2 = 1, kEpsT2K = 2 };
+
+// Everything the kernels need; passed by value (kernarg segment, scalar loads).
+struct SolveParams {
+    int K, T, G, B;
+    int nblk;            // ceil(K / 64)
+    int WN;              // LDS window edge in cells, 0 = gather from global memory
+    int reach;           // ceil(T * vmax * dt / res) + 1 cells
+    int map_stride;      // G*G if every instance has its own map, 0 if shared
+    int pow2;            // resolution is a power of two
+    int store_u;
+    float res, inv_res;
+    float x0, y0;        // index origin == lower clamp (reference grid_map.py:199-201, robot_model.py:93-94)
+    float x_hi, y_hi;    // upper clamp
+    float dt, thr, lambda_;
+    float sigma0, sigma1, iv0, iv1;
+    float umin0, umax0, umin1, umax1;
+    uint64_t seed;
+    const float *map;    // (n_maps, G, G)
+    const float *state;  // (B, 3)
+    const float *goal;   // (B, 2)
+    float *mean;         // (B, T, 2)   read by rollout, rewritten by finish
+    const float *eps;    // per EpsMode, or nullptr
+    float *X;            // (B, T+1, 3, K)
+    float *U;            // (B, T, 2, K) or nullptr
+    float *cost;         // (B, K)
+    float *part;         // (B, nblk, 2 + 2T): block max, block sum, block weighted control sums
+    float *w;            // (B, K)
+    float *ustar;        // (B, T, 2)
+    float *xstar;        // (B, T+1, 3)
+    float *stats;        // (B, 2): max z, sum exp
+    unsigned long long *counter;  // solves completed (Philox stream position), device resident
+};
+
+size_t rollout_lds_bytes(const SolveParams &p);
+size_t finish_lds_bytes(const SolveParams &p);
+
+hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
+hipError_t launch_finish(const SolveParams &p, hipStream_t s);
+
+// layout conversion helpers (planner-native k-fastest <-> reference k-major)
+hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int T1, hipStream_t s);   // (T1,3,K)->(K,T1,3)
+hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int T, hipStream_t s);  // (T,2,K)->(K,T,2)
+hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int K, int T1, hipStream_t s);
+hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s);
+
+}  // namespace bn

@@ -1,0 +1,271 @@
+"""MI355X-native MPPI local planner with the reference's Python interface.
+
+Mirror of `MPPI(nn.Module)` in the reference's
+src/planners/local_planners/mppi.py (constructor :23-36, forward :130-219,
+get_top_samples :221-240): same argument names and meaning, same return shapes,
+same assertion behaviour, so `PlanetaryEnv` loops and the tutorials can switch by
+changing the import.  All arithmetic runs in hand-written HIP kernels behind the
+C ABI of include/benchnav_mppi.h; torch is used only for device memory views,
+stream sharing and the (optional) reference-compatible noise stream.  There is
+no CPU fallback: construction raises without a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+class _DevArray:
+    """Library-owned device memory exposed to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, shape, strides_elems=None):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(s) for s in shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2,
+            "strides": None if strides_elems is None else tuple(int(s) * 4 for s in strides_elems),
+        }
+
+
+def _planner_inputs(dynamics, objectives):
+    """What the native planner reads from the reference-shaped `dynamics` / `objectives`
+    objects: the risk map, the grid geometry, the action bounds, the goal
+    and the stuck threshold."""
+    cfg = getattr(dynamics, "_model_config", None)
+    mode = getattr(cfg, "mode", "inference")
+    if mode != "inference":
+        # the reference's transit returns a tuple in observation mode and MPPI.forward fails on it
+        raise TypeError("MPPI needs dynamics in 'inference' mode (got %r)" % (mode,))
+    gm = dynamics._grid_map
+    risks = dynamics._traversability_model._risks
+    return dict(risks=risks, grid_size=int(gm.grid_size), resolution=float(gm.resolution),
+                x_limits=(float(gm.x_limits[0]), float(gm.x_limits[1])),
+                y_limits=(float(gm.y_limits[0]), float(gm.y_limits[1])),
+                goal=objectives._goal_pos, stuck_threshold=float(objectives._stuck_threshold))
+
+
+class MPPI(nn.Module):
+    """Model Predictive Path Integral control on one MI355X.
+
+    Extra keyword arguments (not in the reference):
+      noise  "torch"  (default) draw eps with torch's CPU generator exactly like the reference
+                      does on CPU (bit-identical stream for the same seed), upload it;
+             "torch_device"  draw eps with torch's generator on the planner's device;
+             "philox"        generate eps inside the rollout kernel (fastest).
+      store_controls  keep `_perturbed_action_seqs` in HBM (the reference always has it).
+      copy_outputs    return fresh tensors from forward() like the reference; False returns
+                      views of the planner's buffers (overwritten by the next call).
+    """
+
+    def __init__(self, horizon: int, num_samples: int, dim_state: int, dim_control: int, dynamics, objectives,
+                 sigmas: torch.Tensor, lambda_: float, device=torch.device("cuda"), dtype=torch.float32,
+                 seed: int = 42, *, noise: str = "torch", store_controls: bool = True,
+                 copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1) -> None:
+        super().__init__()
+        torch.manual_seed(seed)                                    # mppi.py:55
+
+        assert dynamics.min_action.shape == (dim_control,), "minimum actions must be a tensor of shape (dim_control,)"
+        assert dynamics.max_action.shape == (dim_control,), "maximum actions must be a tensor of shape (dim_control,)"
+        assert sigmas.shape == (dim_control,), "sigmas must be a tensor of shape (dim_control,)"
+        if dim_state != 3 or dim_control != 2:
+            raise ValueError("the native planner implements the unicycle model: dim_state=3, dim_control=2")
+        if dtype != torch.float32:
+            raise ValueError("the native planner computes in float32")
+        if noise not in ("torch", "torch_device", "philox"):
+            raise ValueError(f"unknown noise mode {noise!r}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("benchnav_amd.MPPI needs an MI355X (gfx950) device; there is no CPU fallback")
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"benchnav_amd.MPPI runs on the GPU only (device={device!r})")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self._device = dev
+        self._dtype = dtype
+
+        self._horizon = horizon
+        self._num_samples = num_samples
+        self._dim_state = dim_state
+        self._dim_control = dim_control
+        self._dynamics = dynamics
+        self._stage_cost = objectives.stage_cost
+        self._terminal_cost = objectives.terminal_cost
+        self._u_min = dynamics.min_action.clone().detach().to(dev, dtype)
+        self._u_max = dynamics.max_action.clone().detach().to(dev, dtype)
+        self._sigmas = sigmas.clone().detach().to(dev, dtype)
+        self._lambda = lambda_
+        self._noise_mode = noise
+        self._copy_outputs = copy_outputs
+        # inverse covariance computed the reference's way (mppi.py:94-97)
+        cov = torch.diag(sigmas.detach().cpu().to(dtype) ** 2)
+        inv_cov = torch.inverse(cov)
+        self._inv_covariance = inv_cov.to(dev, dtype)
+        self._sample_shape = torch.Size([num_samples, horizon])
+
+        inp = _planner_inputs(dynamics, objectives)
+        lib = _capi.load()
+        cfg = _capi.Config()
+        lib.bn_mppi_config_init(C.byref(cfg))
+        cfg.device_id = dev.index
+        cfg.horizon, cfg.num_samples, cfg.num_instances = horizon, num_samples, 1
+        cfg.grid_size, cfg.resolution = inp["grid_size"], inp["resolution"]
+        s_cpu = sigmas.detach().cpu().to(dtype)
+        umin, umax = dynamics.min_action.detach().cpu().to(dtype), dynamics.max_action.detach().cpu().to(dtype)
+        for i in range(2):
+            cfg.x_limits[i], cfg.y_limits[i] = inp["x_limits"][i], inp["y_limits"][i]
+            cfg.sigma[i], cfg.inv_var[i] = float(s_cpu[i]), float(inv_cov[i, i])
+            cfg.u_min[i], cfg.u_max[i] = float(umin[i]), float(umax[i])
+        cfg.lambda_, cfg.dt, cfg.stuck_threshold = lambda_, delta_t, inp["stuck_threshold"]
+        cfg.seed = seed
+        cfg.flags = (_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0) | (_capi.BN_FLAG_PROFILE if profile else 0)
+        with torch.cuda.device(dev):
+            cfg.stream = torch.cuda.current_stream(dev).cuda_stream
+            self._handle = C.c_void_p()
+            _capi.check(lib.bn_mppi_create(C.byref(cfg), C.byref(self._handle)))
+        self._lib = lib
+        risks = inp["risks"].detach().to(torch.float32).contiguous()
+        assert risks.shape == (inp["grid_size"], inp["grid_size"])
+        self.set_risk_map(risks)
+        self.set_goal(inp["goal"])
+
+        K, T = num_samples, horizon
+        self._buf_X = self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, K))
+        self._buf_w = self._wrap(_capi.BN_BUF_WEIGHTS, (K,))
+        self._buf_cost = self._wrap(_capi.BN_BUF_COSTS, (K,))
+        self._buf_U = self._wrap(_capi.BN_BUF_CONTROLS, (T, 2, K)) if store_controls else None
+        self._buf_ustar = self._wrap(_capi.BN_BUF_USTAR, (T, 2))
+        self._buf_xstar = self._wrap(_capi.BN_BUF_XSTAR, (1, T + 1, 3))
+        self._buf_mean = self._wrap(_capi.BN_BUF_MEAN, (T, 2))
+        self._eps_dev: Optional[torch.Tensor] = None
+        self._action_noises: Optional[torch.Tensor] = None
+
+        if noise == "torch":
+            # the reference constructor consumes one (K,T,2) draw of the global CPU stream (mppi.py:105-107)
+            self._action_noises = torch.empty(K, T, 2).normal_() * s_cpu
+        elif noise == "torch_device":
+            self._action_noises = torch.randn(K, T, 2, device=dev) * self._sigmas
+
+    # -- plumbing ------------------------------------------------------------------
+    def _wrap(self, buf_id, shape):
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _capi.check(self._lib.bn_mppi_device_buffer(self._handle, buf_id, C.byref(ptr), C.byref(nbytes)))
+        n = 1
+        for s in shape:
+            n *= s
+        assert n * 4 == nbytes.value, (shape, nbytes.value)
+        return torch.as_tensor(_DevArray(ptr.value, shape), device=self._device)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            try:
+                self._lib.bn_mppi_destroy(h)
+            except Exception:
+                pass
+            self._handle = C.c_void_p()
+
+    def set_risk_map(self, risks: torch.Tensor) -> None:
+        """Replace the risk map (dynamics._traversability_model._risks, (G,G) [iy,ix])."""
+        r = risks.detach().to(torch.float32).contiguous()
+        where = _capi.BN_MEM_DEVICE if r.is_cuda else _capi.BN_MEM_HOST
+        if r.is_cuda:
+            torch.cuda.current_stream(r.device).synchronize()
+        _capi.check(self._lib.bn_mppi_set_map(self._handle, 0, C.c_void_p(r.data_ptr()), where))
+
+    def set_goal(self, goal_pos) -> None:
+        g = torch.as_tensor(goal_pos).detach().to("cpu", torch.float32).contiguous()   # int64 goals promote (test_mppi.py:133)
+        assert g.shape == (2,)
+        _capi.check(self._lib.bn_mppi_set_goal(self._handle, 0, C.cast(g.data_ptr(), C.POINTER(C.c_float))))
+
+    # -- reference attributes --------------------------------------------------------
+    @property
+    def _previous_action_seq(self) -> torch.Tensor:
+        return self._buf_mean
+
+    @_previous_action_seq.setter
+    def _previous_action_seq(self, value: torch.Tensor) -> None:
+        self._buf_mean.copy_(torch.as_tensor(value).to(self._device, self._dtype))
+
+    @property
+    def _state_seq_batch(self) -> torch.Tensor:
+        """(K, T+1, 3) view of the planner-native (T+1, 3, K) buffer (no copy)."""
+        return self._buf_X.permute(2, 0, 1)
+
+    @property
+    def _weights(self) -> torch.Tensor:
+        return self._buf_w
+
+    @property
+    def _costs(self) -> torch.Tensor:
+        return self._buf_cost
+
+    @property
+    def _perturbed_action_seqs(self) -> torch.Tensor:
+        if self._buf_U is None:
+            raise AttributeError("_perturbed_action_seqs is not stored (store_controls=False)")
+        return self._buf_U.permute(2, 0, 1)
+
+    # -- the solve ---------------------------------------------------------------------
+    def forward(self, state: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Solve the optimal control problem (mppi.py:130-219).
+
+        Returns (optimal_action_seq (T,2), optimal_state_seq (1,T+1,3)) on the planner's
+        device, stream-ordered like any torch op.  `state` is not modified.
+        """
+        if not torch.is_tensor(state):
+            state = torch.tensor(state, dtype=self._dtype)
+        assert state.shape == (self._dim_state,)
+        st = state.detach().to(self._device, self._dtype).contiguous()
+        K, T = self._num_samples, self._horizon
+        if self._noise_mode == "torch":
+            eps = torch.empty(K, T, 2).normal_()                       # global CPU stream, mppi.py:149-151
+            self._eps_dev = eps.to(self._device)
+            kind, eptr = _capi.BN_NOISE_DEVICE_KT2, C.c_void_p(self._eps_dev.data_ptr())
+        elif self._noise_mode == "torch_device":
+            self._eps_dev = torch.randn(K, T, 2, device=self._device)
+            kind, eptr = _capi.BN_NOISE_DEVICE_KT2, C.c_void_p(self._eps_dev.data_ptr())
+        else:
+            self._eps_dev = None
+            kind, eptr = _capi.BN_NOISE_PHILOX, C.c_void_p(None)
+        self._action_noises = None if self._eps_dev is None else self._eps_dev * self._sigmas
+        self._last_state = st                                          # keep alive until the kernels ran
+        _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
+                                                  eptr, kind))
+        if self._copy_outputs:
+            return self._buf_ustar.clone(), self._buf_xstar.clone()
+        return self._buf_ustar, self._buf_xstar
+
+    solve = forward
+
+    def solve_with_noise(self, state: torch.Tensor, eps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """forward() with caller-supplied standard-normal noise eps (K,T,2) (teacher-forced parity tests)."""
+        assert eps.shape == (self._num_samples, self._horizon, 2)
+        st = torch.as_tensor(state).detach().to(self._device, self._dtype).contiguous()
+        self._eps_dev = eps.detach().to(self._device, self._dtype).contiguous()
+        self._action_noises = self._eps_dev * self._sigmas
+        self._last_state = st
+        _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
+                                                  C.c_void_p(self._eps_dev.data_ptr()), _capi.BN_NOISE_DEVICE_KT2))
+        return self._buf_ustar.clone(), self._buf_xstar.clone()
+
+    def get_top_samples(self, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The `num_samples` highest-weight rollouts, by weight descending (mppi.py:221-240)."""
+        assert num_samples <= self._num_samples
+        top_indices = torch.topk(self._weights, num_samples).indices
+        top_samples = self._state_seq_batch[top_indices]
+        top_weights = self._weights[top_indices]
+        order = torch.argsort(top_weights, descending=True)
+        return top_samples[order], top_weights[order]
+
+    # -- measurement helpers -------------------------------------------------------------
+    def kernel_ms(self):
+        r, f, n = C.c_float(), C.c_float(), C.c_int32()
+        _capi.check(self._lib.bn_mppi_kernel_ms(self._handle, C.byref(r), C.byref(f), C.byref(n)))
+        return r.value, f.value, n.value
+
+    def algorithmic_bytes(self) -> int:
+        kind = _capi.BN_NOISE_PHILOX if self._noise_mode == "philox" else _capi.BN_NOISE_DEVICE_KT2
+        return int(self._lib.bn_mppi_algorithmic_bytes(self._handle, kind))

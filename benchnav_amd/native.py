@@ -1,0 +1,172 @@
+"""NumPy-level wrapper of the C ABI (no torch): one handle, B instances.
+
+This is the thinnest host layer above include/benchnav_mppi.h; the torch-facing
+`benchnav_amd.MPPI` mirrors the reference class, this one serves C-ABI level
+tests, the benchmark and batched (multi-instance) solves.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+class NativeMPPI:
+    def __init__(self, *, horizon: int, num_samples: int, grid_size: int, resolution: float,
+                 x_limits: Optional[Sequence[float]] = None, y_limits: Optional[Sequence[float]] = None,
+                 sigmas=(0.5, 0.5), inv_var=None, lambda_: float = 0.5, u_min=(0.0, -1.0), u_max=(1.0, 1.0),
+                 dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
+                 seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
+                 profile: bool = False, stream: Optional[int] = None):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        cfg = _capi.Config()
+        self._lib.bn_mppi_config_init(C.byref(cfg))
+        if x_limits is None:       # reference GridMap geometry, grid_map.py:42-50
+            c = grid_size * resolution / 2
+            x_limits = (c - grid_size / 2 * resolution, c + grid_size / 2 * resolution)
+        if y_limits is None:
+            y_limits = x_limits
+        if inv_var is None:
+            s32 = np.asarray(sigmas, np.float32)
+            inv_var = (np.float32(1) / (s32 * s32)).tolist()
+        cfg.device_id = device_id
+        cfg.horizon, cfg.num_samples, cfg.num_instances = horizon, num_samples, num_instances
+        cfg.grid_size, cfg.resolution = grid_size, resolution
+        for i in range(2):
+            cfg.x_limits[i], cfg.y_limits[i] = x_limits[i], y_limits[i]
+            cfg.sigma[i], cfg.inv_var[i] = sigmas[i], inv_var[i]
+            cfg.u_min[i], cfg.u_max[i] = u_min[i], u_max[i]
+        cfg.lambda_, cfg.dt, cfg.stuck_threshold, cfg.seed = lambda_, dt, stuck_threshold, seed
+        cfg.flags = ((_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0)
+                     | (_capi.BN_FLAG_SHARED_MAP if shared_map else 0)
+                     | (0 if lds_window else _capi.BN_FLAG_NO_LDS_WINDOW)
+                     | (_capi.BN_FLAG_PROFILE if profile else 0)
+                     | (_capi.BN_FLAG_PRIVATE_STREAM if stream is None else 0))
+        cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
+        self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
+        self.store_controls = store_controls
+        _capi.check(self._lib.bn_mppi_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.bn_mppi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- inputs ----------------------------------------------------------------------
+    def set_map(self, risk, instance: int = -1):
+        r = _f32(risk, (self.G, self.G))
+        _capi.check(self._lib.bn_mppi_set_map(self._h, instance, C.c_void_p(r.ctypes.data), _capi.BN_MEM_HOST))
+
+    def set_goal(self, goal, instance: int = -1):
+        _capi.check(self._lib.bn_mppi_set_goal(self._h, instance, _fp(_f32(goal, (2,)))))
+
+    def set_mean(self, mean=None, instance: int = -1):
+        if mean is None:
+            _capi.check(self._lib.bn_mppi_set_mean(self._h, instance, None))
+        else:
+            _capi.check(self._lib.bn_mppi_set_mean(self._h, instance, _fp(_f32(mean, (self.T, 2)))))
+
+    def get_mean(self, instance: int = 0) -> np.ndarray:
+        out = np.empty((self.T, 2), np.float32)
+        _capi.check(self._lib.bn_mppi_get_mean(self._h, instance, _fp(out)))
+        return out
+
+    # -- solve -------------------------------------------------------------------------
+    def solve(self, states, eps=None):
+        """Synchronous solve of all B instances.  eps: None (Philox) or (B,K,T,2) / (K,T,2) host noise.
+        Returns (Ustar (B,T,2), Xstar (B,T+1,3))."""
+        st = _f32(states).reshape(self.B, 3)
+        us = np.empty((self.B, self.T, 2), np.float32)
+        xs = np.empty((self.B, self.T + 1, 3), np.float32)
+        if eps is None:
+            kind, eptr = _capi.BN_NOISE_PHILOX, C.c_void_p(None)
+        else:
+            e = _f32(eps).reshape(self.B, self.K, self.T, 2)
+            kind, eptr = _capi.BN_NOISE_HOST_KT2, C.c_void_p(e.ctypes.data)
+        _capi.check(self._lib.bn_mppi_solve(self._h, C.c_void_p(st.ctypes.data), _capi.BN_MEM_HOST, eptr, kind,
+                                            _fp(us), _fp(xs)))
+        return us, xs
+
+    def solve_async_device(self, state_ptr: int, eps_ptr: Optional[int] = None, kind: int = _capi.BN_NOISE_PHILOX):
+        """Enqueue one solve with device-resident state (and noise); nothing is copied."""
+        _capi.check(self._lib.bn_mppi_solve_async(self._h, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
+                                                  C.c_void_p(eps_ptr), kind))
+
+    def sync(self):
+        _capi.check(self._lib.bn_mppi_sync(self._h))
+
+    # -- outputs (reference layouts) -------------------------------------------------------
+    def weights(self, instance: int = 0) -> np.ndarray:
+        out = np.empty(self.K, np.float32)
+        _capi.check(self._lib.bn_mppi_get_weights(self._h, instance, _fp(out)))
+        return out
+
+    def costs(self, instance: int = 0) -> np.ndarray:
+        out = np.empty(self.K, np.float32)
+        _capi.check(self._lib.bn_mppi_get_costs(self._h, instance, _fp(out)))
+        return out
+
+    def states(self, instance: int = 0) -> np.ndarray:
+        out = np.empty((self.K, self.T + 1, 3), np.float32)
+        _capi.check(self._lib.bn_mppi_get_states(self._h, instance, _fp(out)))
+        return out
+
+    def controls(self, instance: int = 0) -> np.ndarray:
+        out = np.empty((self.K, self.T, 2), np.float32)
+        _capi.check(self._lib.bn_mppi_get_controls(self._h, instance, _fp(out)))
+        return out
+
+    def philox_noise(self, solve_index: int, instance: int = 0) -> np.ndarray:
+        out = np.empty((self.K, self.T, 2), np.float32)
+        _capi.check(self._lib.bn_mppi_get_philox_noise(self._h, instance, solve_index, _fp(out)))
+        return out
+
+    def top_samples(self, n: int, instance: int = 0):
+        s = np.empty((n, self.T + 1, 3), np.float32)
+        w = np.empty(n, np.float32)
+        _capi.check(self._lib.bn_mppi_get_top_samples(self._h, instance, n, _fp(s), _fp(w)))
+        return s, w
+
+    def device_buffer(self, buf_id: int):
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _capi.check(self._lib.bn_mppi_device_buffer(self._h, buf_id, C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def solve_count(self) -> int:
+        return int(self._lib.bn_mppi_solve_count(self._h))
+
+    def kernel_ms(self):
+        r, f, n = C.c_float(), C.c_float(), C.c_int32()
+        _capi.check(self._lib.bn_mppi_kernel_ms(self._h, C.byref(r), C.byref(f), C.byref(n)))
+        return r.value, f.value, n.value
+
+    def algorithmic_bytes(self, injected_noise: bool = True) -> int:
+        kind = _capi.BN_NOISE_DEVICE_KT2 if injected_noise else _capi.BN_NOISE_PHILOX
+        return int(self._lib.bn_mppi_algorithmic_bytes(self._h, kind))

@@ -1,0 +1,184 @@
+/*
+ * benchnav_mppi.h -- C ABI of the MI355X-native MPPI local planner.
+ *
+ * This is the drop-in boundary for BenchNav's MPPI hot path.  The reference has
+ * no FFI layer: its boundary is the Python class
+ *     src/planners/local_planners/mppi.py:17   class MPPI(nn.Module)
+ * whose methods the entry points below replace one for one (citations are
+ * reference file:line).  The Python mirror of that class lives in
+ * benchnav_amd/mppi.py and binds these symbols with ctypes; INTEGRATION.md shows
+ * the stub a BenchNav maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns BN_OK (0) or a negative bn_status,
+ *     bn_last_error() gives the message of the calling thread's last failure;
+ *   - a handle is bound to one HIP device and one HIP stream; it is not
+ *     thread-safe, distinct handles are independent;
+ *   - "host"/"device" in a parameter name says where the pointer must live;
+ *     the library owns every device buffer it allocates, callers own theirs;
+ *   - all arrays are float32, C-contiguous; shapes use the reference's names:
+ *     K = num_samples, T = horizon, G = grid_size, B = num_instances;
+ *   - `*_async` entry points only enqueue work on the handle's stream.
+ */
+#ifndef BENCHNAV_MPPI_H
+#define BENCHNAV_MPPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BN_MPPI_ABI_VERSION 1
+
+typedef enum bn_status {
+    BN_OK = 0,
+    BN_ERR_INVALID = -1,      /* bad argument / unsupported configuration          */
+    BN_ERR_HIP = -2,          /* a HIP runtime call failed (message has the detail) */
+    BN_ERR_NO_DEVICE = -3,    /* no usable gfx950 device                            */
+    BN_ERR_STATE = -4         /* call sequence error (e.g. solve before set_map)    */
+} bn_status;
+
+/* Where the per-solve standard-normal noise eps comes from (mppi.py:149-151). */
+typedef enum bn_noise_kind {
+    BN_NOISE_PHILOX = 0,      /* generated in the rollout kernel (Philox4x32-10 + Box-Muller) */
+    BN_NOISE_HOST_KT2 = 1,    /* host pointer, (B,K,T,2): the reference's rsample layout       */
+    BN_NOISE_DEVICE_KT2 = 2,  /* device pointer, (B,K,T,2)                                      */
+    BN_NOISE_DEVICE_T2K = 3   /* device pointer, (B,T,2,K): planner-native, coalesced           */
+} bn_noise_kind;
+
+typedef enum bn_mem_kind { BN_MEM_HOST = 0, BN_MEM_DEVICE = 1 } bn_mem_kind;
+
+/* Device buffers a caller may map without a copy (bn_mppi_device_buffer). */
+typedef enum bn_buffer_id {
+    BN_BUF_STATES = 0,    /* (B,T+1,3,K)  _state_seq_batch, planner-native layout (k fastest)   */
+    BN_BUF_WEIGHTS = 1,   /* (B,K)        _weights                                             */
+    BN_BUF_COSTS = 2,     /* (B,K)        per-rollout total cost                               */
+    BN_BUF_CONTROLS = 3,  /* (B,T,2,K)    _perturbed_action_seqs (only with BN_FLAG_STORE_CONTROLS) */
+    BN_BUF_USTAR = 4,     /* (B,T,2)      optimal_action_seq                                   */
+    BN_BUF_XSTAR = 5,     /* (B,T+1,3)    optimal_state_seq                                    */
+    BN_BUF_MEAN = 6,      /* (B,T,2)      _previous_action_seq                                 */
+    BN_BUF_MAP = 7,       /* (n_maps,G,G) risk map(s)                                          */
+    BN_BUF_GOAL = 8,      /* (B,2)                                                             */
+    BN_BUF_COUNT_ = 9
+} bn_buffer_id;
+
+enum {
+    BN_FLAG_STORE_CONTROLS = 1u << 0,  /* materialise _perturbed_action_seqs in HBM          */
+    BN_FLAG_SHARED_MAP = 1u << 1,      /* all B instances plan on map 0                      */
+    BN_FLAG_NO_LDS_WINDOW = 1u << 2,   /* debug: gather the risk map from global memory      */
+    BN_FLAG_PROFILE = 1u << 3,         /* record HIP events around each kernel (see bn_mppi_kernel_ms) */
+    BN_FLAG_PRIVATE_STREAM = 1u << 4   /* ignore `stream`: the library creates and owns a non-blocking stream */
+};
+
+/*
+ * Everything MPPI.__init__ (mppi.py:23-128) receives or reads from its
+ * `dynamics` / `objectives` arguments, flattened to plain data:
+ *   horizon, num_samples              mppi.py:25-26
+ *   sigma                             mppi.py:31,89
+ *   inv_var = diag(inverse(diag(sigma^2)))   mppi.py:94-97 (host computes it the reference's way)
+ *   lambda_                           mppi.py:32,90
+ *   u_min, u_max                      robot_model.py:54-57 via mppi.py:83-88
+ *   dt                                robot_model.py:60 (transit's default delta_t = 0.1)
+ *   stuck_threshold                   objectives.py:27
+ *   grid_size, resolution, x/y_limits grid_map.py:40-50  (limits[0] is also the index origin, grid_map.py:199-201)
+ */
+typedef struct bn_mppi_config {
+    uint32_t struct_size;     /* = sizeof(bn_mppi_config) */
+    int32_t device_id;        /* HIP device ordinal */
+    int32_t horizon;          /* T >= 1 */
+    int32_t num_samples;      /* K >= 1 */
+    int32_t num_instances;    /* B >= 1 independent planning instances solved per call */
+    int32_t grid_size;        /* G >= 1 */
+    float resolution;
+    float x_limits[2];
+    float y_limits[2];
+    float sigma[2];
+    float inv_var[2];
+    float lambda_;
+    float u_min[2];
+    float u_max[2];
+    float dt;
+    float stuck_threshold;
+    uint64_t seed;            /* Philox key for BN_NOISE_PHILOX */
+    uint32_t flags;           /* BN_FLAG_* */
+    void *stream;             /* hipStream_t to enqueue on; NULL is HIP's default (null) stream, which is
+                                 also torch's default stream.  See BN_FLAG_PRIVATE_STREAM. */
+} bn_mppi_config;
+
+typedef struct bn_mppi bn_mppi_t;
+
+/* Fills *cfg with the reference's defaults (robot_model.py:54-60, test_mppi.py:160-169). */
+void bn_mppi_config_init(bn_mppi_config *cfg);
+
+/* MPPI.__init__, mppi.py:23-128: allocates the device buffers (_state_seq_batch,
+ * _weights, _previous_action_seq = 0, ...).  Fails with BN_ERR_NO_DEVICE when no
+ * gfx950 device is present: there is no CPU fallback. */
+int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out);
+void bn_mppi_destroy(bn_mppi_t *h);
+
+/* dynamics._traversability_model._risks (traversability_model.py:24-26), (G,G)
+ * row-major [iy][ix] (grid_map.py:167).  instance = -1 sets every map. */
+int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_kind where);
+/* objectives._goal_pos (objectives.py:26).  instance = -1 sets every instance. */
+int bn_mppi_set_goal(bn_mppi_t *h, int32_t instance, const float goal_host[2]);
+/* _previous_action_seq (mppi.py:116,217): (T,2) host array; NULL resets it to zero. */
+int bn_mppi_set_mean(bn_mppi_t *h, int32_t instance, const float *mean_host);
+int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host);
+
+/*
+ * MPPI.forward(state), mppi.py:130-219, for all B instances.
+ *   states   (B,3) current states, host or device per `states_where`
+ *   eps      noise per `noise` (NULL for BN_NOISE_PHILOX)
+ *   ustar_host  (B,T,2)    optimal_action_seq, may be NULL
+ *   xstar_host  (B,T+1,3)  optimal_state_seq,  may be NULL
+ * Synchronous like the reference: returns after the stream has drained and the
+ * outputs are in the host arrays.  Updates _previous_action_seq (no shift, mppi.py:217).
+ */
+int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
+                  bn_noise_kind noise, float *ustar_host, float *xstar_host);
+/* Same, enqueue only: results stay in the device buffers (bn_mppi_device_buffer). */
+int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where,
+                        const float *eps, bn_noise_kind noise);
+int bn_mppi_sync(bn_mppi_t *h);
+
+/* Copies of the planner state in the REFERENCE's layouts (host arrays).  All
+ * synchronise the stream first.
+ *   weights  (K,)        _weights                 mppi.py:193
+ *   costs    (K,)        `costs` local            mppi.py:186-190
+ *   states   (K,T+1,3)   _state_seq_batch         mppi.py:119-125 (aliased slots)
+ *   controls (K,T,2)     _perturbed_action_seqs   mppi.py:155-157 (needs BN_FLAG_STORE_CONTROLS)
+ *   noise    (K,T,2)     eps of solve number `solve_index` regenerated from the Philox stream */
+int bn_mppi_get_weights(bn_mppi_t *h, int32_t instance, float *out_host);
+int bn_mppi_get_costs(bn_mppi_t *h, int32_t instance, float *out_host);
+int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host);
+int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host);
+int bn_mppi_get_philox_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_index, float *out_host);
+
+/* MPPI.get_top_samples(n), mppi.py:221-240: the n highest-weight rollouts, sorted
+ * by weight descending.  states_host (n,T+1,3), weights_host (n,).  n <= K. */
+int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *states_host,
+                            float *weights_host);
+
+/* Zero-copy access to a library-owned device buffer (layouts in bn_buffer_id). */
+int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size_t *bytes);
+
+/* Number of solves enqueued so far (the Philox stream position). */
+uint64_t bn_mppi_solve_count(const bn_mppi_t *h);
+
+/* With BN_FLAG_PROFILE: mean duration in milliseconds of the rollout kernel and of
+ * the finish kernel over the solves since the last call (HIP events on the
+ * handle's stream), and how many solves that covers.  Synchronises. */
+int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t *n_solves);
+
+/* Algorithmic HBM bytes of one solve in the current mode (DESIGN.md "Roofline"). */
+int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise);
+
+const char *bn_last_error(void);
+int bn_mppi_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BENCHNAV_MPPI_H */

@@ -1,0 +1,112 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol the header declares.
+No compute call is made (there is no GPU here); creation must fail loudly, not fall back."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from benchnav_amd import _capi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "benchnav_mppi.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_for_gfx950():
+    path = build.build_library()
+    assert os.path.exists(path)
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", path], capture_output=True, text=True)
+    if out.returncode == 0 and out.stdout:
+        assert "gfx950" in out.stdout or True   # offload bundle is embedded; arch is checked below
+    blob = open(path, "rb").read()
+    assert b"gfx950" in blob, "no gfx950 code object embedded in the library"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _capi.load()
+    decl = declared_functions()
+    assert len(decl) >= 20
+    assert set(decl) == set(_capi.SYMBOLS), (set(decl) ^ set(_capi.SYMBOLS))
+    for name in decl:
+        assert getattr(lib, name) is not None
+
+
+def test_config_struct_matches_header_layout():
+    lib = _capi.load()
+    cfg = _capi.Config()
+    lib.bn_mppi_config_init(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(_capi.Config)
+    assert (cfg.horizon, cfg.num_samples, cfg.num_instances) == (50, 1024, 1)
+    assert (cfg.u_min[0], cfg.u_min[1], cfg.u_max[0], cfg.u_max[1]) == (0.0, -1.0, 1.0, 1.0)   # robot_model.py:54-57
+    assert abs(cfg.dt - 0.1) < 1e-7 and cfg.seed == 42
+    assert lib.bn_mppi_abi_version() == _capi.ABI_VERSION
+
+
+def test_abi_rejects_wrong_struct_size_and_null():
+    lib = _capi.load()
+    cfg = _capi.Config()
+    lib.bn_mppi_config_init(C.byref(cfg))
+    cfg.struct_size = 4
+    h = C.c_void_p()
+    assert lib.bn_mppi_create(C.byref(cfg), C.byref(h)) == _capi.BN_ERR_INVALID
+    assert b"struct_size" in lib.bn_last_error()
+    assert lib.bn_mppi_create(None, C.byref(h)) == _capi.BN_ERR_INVALID
+    assert lib.bn_mppi_sync(None) == _capi.BN_ERR_INVALID
+    assert lib.bn_mppi_solve_count(None) == 0
+    lib.bn_mppi_destroy(None)
+
+
+def test_invalid_configs_are_rejected_before_touching_the_device():
+    lib = _capi.load()
+    for field, value in (("horizon", 0), ("num_samples", 0), ("grid_size", 0), ("resolution", 0.0), ("lambda_", 0.0)):
+        cfg = _capi.Config()
+        lib.bn_mppi_config_init(C.byref(cfg))
+        setattr(cfg, field, value)
+        h = C.c_void_p()
+        assert lib.bn_mppi_create(C.byref(cfg), C.byref(h)) == _capi.BN_ERR_INVALID, field
+    cfg = _capi.Config()
+    lib.bn_mppi_config_init(C.byref(cfg))
+    cfg.x_limits[1] = 10.0            # 64 cells of 0.5 m do not fit in 10 m
+    h = C.c_void_p()
+    assert lib.bn_mppi_create(C.byref(cfg), C.byref(h)) == _capi.BN_ERR_INVALID
+    assert b"limits" in lib.bn_last_error()
+
+
+def _gpu_present():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_gpu_present(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    lib = _capi.load()
+    cfg = _capi.Config()
+    lib.bn_mppi_config_init(C.byref(cfg))
+    h = C.c_void_p()
+    assert lib.bn_mppi_create(C.byref(cfg), C.byref(h)) == _capi.BN_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.bn_last_error()
+    import torch
+    from benchnav_amd.mppi import MPPI
+
+    class Dyn:
+        min_action = torch.tensor([0.0, -1.0]); max_action = torch.tensor([1.0, 1.0])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MPPI(5, 8, 3, 2, Dyn(), object(), torch.tensor([0.5, 0.5]), 0.5)
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (or any CPU restatement)."""
+    pkg = os.path.join(ROOT, "benchnav_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "mppi_oracle" not in text and "liboracle" not in text, f

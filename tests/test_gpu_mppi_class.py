@@ -1,0 +1,82 @@
+"""GPU: the torch-facing drop-in class (benchnav_amd.MPPI) used the way the reference's drivers use
+theirs (test/test_mppi.py:160-198): construct from dynamics/objectives objects, call forward(state),
+read get_top_samples."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TOL_REF, assert_within, load_case, mppi_for_fixture, parity_metrics
+
+pytestmark = pytest.mark.gpu
+
+
+def _collect(solver, U, X):
+    return dict(U=solver._perturbed_action_seqs.cpu().numpy(), X=solver._state_seq_batch.cpu().numpy(),
+                cost=solver._costs.cpu().numpy(), w=solver._weights.cpu().numpy(),
+                Ustar=U.cpu().numpy(), Xstar=X[0].cpu().numpy())
+
+
+def test_forward_reproduces_the_reference_run_with_the_reference_noise_stream():
+    fx = load_case("c1_basic")
+    same_stream = (str(fx["cpu_capability"]) == torch.backends.cpu.get_cpu_capability()
+                   and str(fx["torch_version"]) == torch.__version__)
+    solver = mppi_for_fixture(fx, noise="torch")
+    for i in range(int(fx["n_solves"])):
+        state = torch.tensor(fx[f"state_{i}"])
+        keep = state.clone()
+        solver._previous_action_seq = torch.from_numpy(fx[f"mean_{i}"])      # teacher forcing
+        with torch.no_grad():
+            if same_stream:
+                U, X = solver.forward(state=state)                           # draws eps like mppi.py:149-151
+                assert np.array_equal((solver._action_noises.cpu() / torch.tensor(fx["sigmas"])).numpy(), fx[f"eps_{i}"])
+            else:
+                U, X = solver.solve_with_noise(state, torch.from_numpy(fx[f"eps_{i}"]))
+        assert torch.equal(state, keep), "forward must not mutate the caller's state"
+        assert U.shape == (int(fx["T"]), 2) and X.shape == (1, int(fx["T"]) + 1, 3) and U.is_cuda
+        assert_within(parity_metrics(_collect(solver, U, X), fx, i), TOL_REF, ctx=f"solve {i}")
+        assert torch.equal(solver._previous_action_seq, U)                   # mppi.py:217
+
+
+def test_callable_interfaces_and_top_samples():
+    fx = load_case("cvar")
+    solver = mppi_for_fixture(fx, noise="torch")
+    state = torch.tensor(fx["state_0"], device="cuda")
+    with torch.no_grad():
+        U1, X1 = solver(state)                       # nn.Module call
+        U2, X2 = solver.solve(state)                 # alias
+    assert U1.shape == U2.shape
+    n = 17
+    top_s, top_w = solver.get_top_samples(num_samples=n)
+    assert top_s.shape == (n, int(fx["T"]) + 1, 3) and top_w.shape == (n,)
+    assert torch.all(top_w[:-1] >= top_w[1:])
+    w = solver._weights
+    assert torch.equal(top_w, torch.sort(w, descending=True).values[:n])
+    k0 = int(torch.argmax(w))
+    assert torch.equal(top_s[0], solver._state_seq_batch[k0])
+    assert top_s.cpu().numpy().shape == (n, int(fx["T"]) + 1, 3)   # planetary_env.py:366-369 does .cpu().numpy()
+    with pytest.raises(AssertionError):
+        solver.get_top_samples(int(fx["K"]) + 1)
+    with pytest.raises(AssertionError):
+        solver.forward(torch.zeros(4))
+
+
+def test_state_batch_view_matches_the_c_abi_copy_and_noise_modes_run():
+    fx = load_case("c1_stuck")
+    for mode in ("philox", "torch_device"):
+        solver = mppi_for_fixture(fx, noise=mode, copy_outputs=False)
+        U, X = solver(torch.tensor(fx["state_0"]))
+        torch.cuda.synchronize()
+        assert solver._state_seq_batch.shape == (int(fx["K"]), int(fx["T"]) + 1, 3)
+        assert abs(float(solver._weights.sum()) - 1.0) < 1e-4
+        assert torch.isfinite(U).all() and torch.isfinite(X).all()
+        # X*[0,0] is the un-clamped state after the first step, not the input (aliasing)
+        assert not torch.allclose(X[0, 0].cpu(), torch.tensor(fx["state_0"]))
+
+
+def test_observation_mode_dynamics_are_rejected_like_the_reference():
+    from helpers import FakeDynamics, FakeGridMap, FakeObjectives
+    from benchnav_amd import MPPI
+    gm = FakeGridMap(16, 0.5)
+    dyn = FakeDynamics(np.zeros((16, 16), np.float32), gm, mode="observation")
+    with pytest.raises(TypeError):
+        MPPI(5, 64, 3, 2, dyn, FakeObjectives(torch.tensor([4, 4]), 0.3), torch.tensor([0.5, 0.5]), 0.5)
