@@ -56,6 +56,7 @@ SYMBOLS = {
     "bn_mppi_get_top_samples": (C.c_int, [_H, C.c_int32, C.c_int32, _FP, _FP]),
     "bn_mppi_device_buffer": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bn_mppi_solve_count": (C.c_uint64, [_H]),
+    "bn_mppi_row_pitch": (C.c_int32, [_H]),
     "bn_mppi_kernel_ms": (C.c_int, [_H, _FP, _FP, C.POINTER(C.c_int32)]),
     "bn_mppi_algorithmic_bytes": (C.c_int64, [_H, C.c_int]),
     "bn_last_error": (C.c_char_p, []),

@@ -17,6 +17,8 @@ constexpr float kTwoPi = 6.28318548202514648f;
 // n = rint(x*2/pi); 3-term Cody-Waite reduction by pi/2 with fma; Cephes single
 // precision kernels on [-pi/4, pi/4]; compensated 1 - s/2 for the cosine.
 // Max error 1.5 ulp on |x| <= pi + 0.1 (measured against fp64).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
 {
     const float fn = __builtin_rintf(x * 0.636619772367581343f);
@@ -24,20 +26,24 @@ __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
     r = __builtin_fmaf(-fn, 4.837512969970703125e-4f, r);
     r = __builtin_fmaf(-fn, 7.54978995489188216e-8f, r);
     const float s = r * r;
-    float p = __builtin_fmaf(-1.9515295891e-4f, s, 8.3321608736e-3f);
-    p = __builtin_fmaf(p, s, -1.6666654611e-1f);
-    const float S = __builtin_fmaf(p * s, r, r);
-    float q = __builtin_fmaf(2.443315711809948e-5f, s, -1.388731625493765e-3f);
-    q = __builtin_fmaf(q, s, 4.166664568298827e-2f);
+    // the sine (x) and cosine (y) polynomials share their shape: evaluate them as one packed stream
+    const v2f s2 = {s, s};
+    v2f pq = __builtin_elementwise_fma(v2f{-1.9515295891e-4f, 2.443315711809948e-5f}, s2,
+                                       v2f{8.3321608736e-3f, -1.388731625493765e-3f});
+    pq = __builtin_elementwise_fma(pq, s2, v2f{-1.6666654611e-1f, 4.166664568298827e-2f});
+    pq = pq * s2;
+    const float S = __builtin_fmaf(pq.x, r, r);
     const float hz = 0.5f * s;
     const float w = 1.0f - hz;
-    const float C = w + __builtin_fmaf(q * s, s, (1.0f - w) - hz);
+    const float C = w + __builtin_fmaf(pq.y, s, (1.0f - w) - hz);
     const int n = (int)fn;
-    const float a = (n & 1) ? C : S;          // |sin|-side value
-    const float b = (n & 1) ? S : C;          // |cos|-side value
-    // quadrant signs: sin negative for n&3 in {2,3}; cos negative for n&3 in {1,2}
-    sn = (n & 2) ? -a : a;
-    cs = ((n + 1) & 2) ? -b : b;
+    const bool odd = (n & 1) != 0;
+    const float a = odd ? C : S;              // |sin|-side value
+    const float b = odd ? S : C;              // |cos|-side value
+    // quadrant signs as sign-bit flips: sin negative for n&3 in {2,3}; cos negative for n&3 in {1,2}
+    const uint32_t h = (uint32_t)n << 30;     // bit 1 of n -> bit 31
+    sn = __uint_as_float(__float_as_uint(a) ^ (h & 0x80000000u));
+    cs = __uint_as_float(__float_as_uint(b) ^ ((h + 0x40000000u) & 0x80000000u));
 }
 
 // torch.remainder(a, b), b > 0: fmod (exact) then the divisor-sign fix.  The
@@ -58,19 +64,25 @@ __device__ __forceinline__ float wrap_angle(float th)
     return py_mod_pos(th + kPi, kTwoPi) - kPi;
 }
 
-__device__ __forceinline__ float clampf(float v, float lo, float hi)
+// Same value, branch-free, valid for theta + pi in (-2 pi, 4 pi): every step after the first,
+// because the previous wrap left theta in [-pi, pi] and |trav * omega * dt| < pi (checked at create).
+__device__ __forceinline__ float wrap_angle_near(float th)
 {
-    return fminf(fmaxf(v, lo), hi);
+    const float a = th + kPi;
+    float m = (a >= kTwoPi) ? (a - kTwoPi) : a;      // exact (Sterbenz), == fmod
+    m = (a < 0.0f) ? (a + kTwoPi) : m;               // the divisor-sign fix of torch.remainder
+    return m - kPi;
 }
 
-// ((p - origin) / res).floor().int().clamp(0, G-1)    reference grid_map.py:195-209
-// POW2: res is a power of two, so multiplying by 1/res is bit-identical to dividing.
-template <bool POW2>
-__device__ __forceinline__ int cell_index(float p, float origin, float res, float inv_res, int gmax)
+// min(max(v, lo), hi) in one v_med3_f32 (lo <= hi)
+__device__ __forceinline__ float clampf(float v, float lo, float hi)
 {
-    const float q = POW2 ? (p - origin) * inv_res : (p - origin) / res;
-    const int i = (int)floorf(q);             // v_cvt_i32_f32 saturates
-    return min(max(i, 0), gmax);
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi)
+{
+    return min(max(v, lo), hi);
 }
 
 // ---- Philox4x32-10 + Box-Muller ------------------------------------------------
@@ -101,15 +113,17 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, fl
     z1 = rad * sn;
 }
 
-// eps[b][k][t][0..1] for solve number `solve` of the stream keyed by `seed`.
-// Counter = (k, t | b<<16 .. , solve_lo, solve_hi): one Philox block per (k, t-pair).
+// The library's own noise stream (BN_NOISE_PHILOX): one Philox block per (instance b, rollout k,
+// step pair p) of solve number `solve`, key = seed.  Pair p holds the (v, omega) noise of steps
+// 2p-1 and 2p (step 0 is the second half of pair 0), so the rollout loop, which peels step 0,
+// consumes whole pairs per chunk.
 __device__ __forceinline__ void philox_eps_pair(uint64_t seed, uint64_t solve, uint32_t b, uint32_t k,
-                                                uint32_t tpair, float e[4])
+                                                uint32_t pair, float e[4])
 {
-    const u32x4 r = philox4x32_10(u32x4{k, tpair, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
+    const u32x4 r = philox4x32_10(u32x4{k, pair, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
-    box_muller(r.x, r.y, e[0], e[1]);   // step 2*tpair:   (v, omega) noise
-    box_muller(r.z, r.w, e[2], e[3]);   // step 2*tpair+1
+    box_muller(r.x, r.y, e[0], e[1]);   // step 2*pair-1: (v, omega) noise
+    box_muller(r.z, r.w, e[2], e[3]);   // step 2*pair
 }
 
 }  // namespace bn

@@ -75,10 +75,10 @@ size_t buffer_bytes(const bn_mppi *h, bn_buffer_id id)
 {
     const size_t B = h->p.B, K = h->p.K, T = h->p.T, G = h->p.G;
     switch (id) {
-    case BN_BUF_STATES: return B * (T + 1) * 3 * K * 4;
+    case BN_BUF_STATES: return B * (T + 1) * 3 * (size_t)h->p.Kp * 4;
     case BN_BUF_WEIGHTS: return B * K * 4;
     case BN_BUF_COSTS: return B * K * 4;
-    case BN_BUF_CONTROLS: return h->d_U ? B * T * 2 * K * 4 : 0;
+    case BN_BUF_CONTROLS: return h->d_U ? B * T * 2 * (size_t)h->p.Kp * 4 : 0;
     case BN_BUF_USTAR: return B * T * 2 * 4;
     case BN_BUF_XSTAR: return B * (T + 1) * 3 * 4;
     case BN_BUF_MEAN: return B * T * 2 * 4;
@@ -148,6 +148,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     for (int d = 0; d < 2; ++d)
         if (!(cfg->u_min[d] <= cfg->u_max[d]) || !(cfg->sigma[d] >= 0.0f))
             return fail(BN_ERR_INVALID, "need u_min <= u_max and sigma >= 0");
+    // After the first step the heading wrap runs in its branch-free near form (bn_device_math.h),
+    // valid while one step turns by less than pi.
+    if (!((double)cfg->dt * std::max(std::fabs((double)cfg->u_min[1]), std::fabs((double)cfg->u_max[1])) < 3.0))
+        return fail(BN_ERR_INVALID, "dt * max|omega| must stay below 3 rad per step");
     // The kernels share one gather between stage cost t and transit t+1; that needs the upper clamp
     // to land in the last cell, as it does for every reference GridMap (grid_map.py:42-50).
     const float span_x = (cfg->x_limits[1] - cfg->x_limits[0]) / cfg->resolution;
@@ -172,6 +176,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     bn::SolveParams &p = h->p;
     p.K = cfg->num_samples; p.T = cfg->horizon; p.G = cfg->grid_size; p.B = cfg->num_instances;
     p.nblk = (p.K + bn::kRolloutsPerBlock - 1) / bn::kRolloutsPerBlock;
+    p.Kp = p.nblk * bn::kRolloutsPerBlock;
     p.res = cfg->resolution; p.inv_res = 1.0f / cfg->resolution;
     p.pow2 = is_pow2_float(cfg->resolution) ? 1 : 0;
     p.x0 = cfg->x_limits[0]; p.y0 = cfg->y_limits[0];
@@ -211,8 +216,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     alloc(&h->d_state, B * 3 * 4);
     alloc(&h->d_goal, B * 2 * 4);
     alloc(&h->d_mean, B * T * 2 * 4);
-    alloc(&h->d_X, B * (T + 1) * 3 * K * 4);
-    if (p.store_u) alloc(&h->d_U, B * T * 2 * K * 4);
+    alloc(&h->d_X, B * (T + 1) * 3 * (size_t)p.Kp * 4);
+    if (p.store_u) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
     alloc(&h->d_cost, B * K * 4);
     alloc(&h->d_part, B * (size_t)p.nblk * (2 + 2 * T) * 4);
     alloc(&h->d_w, B * K * 4);
@@ -419,9 +424,10 @@ int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host)
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
-    const size_t K = h->p.K, T1 = h->p.T + 1, n = K * T1 * 3;
+    const size_t K = h->p.K, Kp = h->p.Kp, T1 = h->p.T + 1, n = K * T1 * 3;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
-    BN_HIP(bn::launch_states_to_reference(h->d_X + (size_t)instance * n, h->d_scratch, (int)K, (int)T1, h->stream));
+    BN_HIP(bn::launch_states_to_reference(h->d_X + (size_t)instance * Kp * T1 * 3, h->d_scratch, (int)K, (int)Kp, (int)T1,
+                                          h->stream));
     BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
     return BN_OK;
@@ -433,9 +439,10 @@ int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host)
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     if (!h->d_U) return fail(BN_ERR_STATE, "controls are only stored with BN_FLAG_STORE_CONTROLS");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
-    const size_t K = h->p.K, T = h->p.T, n = K * T * 2;
+    const size_t K = h->p.K, Kp = h->p.Kp, T = h->p.T, n = K * T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
-    BN_HIP(bn::launch_controls_to_reference(h->d_U + (size_t)instance * n, h->d_scratch, (int)K, (int)T, h->stream));
+    BN_HIP(bn::launch_controls_to_reference(h->d_U + (size_t)instance * Kp * T * 2, h->d_scratch, (int)K, (int)Kp, (int)T,
+                                            h->stream));
     BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
     return BN_OK;
@@ -478,7 +485,7 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
     }
     if (int rc = ensure_scratch(h, (size_t)n * T1 * 3 * 4)) return rc;
     BN_HIP(hipMemcpyAsync(h->d_idx, idx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    BN_HIP(bn::launch_gather_states(h->d_X + (size_t)instance * K * T1 * 3, h->d_idx, h->d_scratch, n, (int)K,
+    BN_HIP(bn::launch_gather_states(h->d_X + (size_t)instance * h->p.Kp * T1 * 3, h->d_idx, h->d_scratch, n, h->p.Kp,
                                     (int)T1, h->stream));
     BN_HIP(hipMemcpyAsync(states_host, h->d_scratch, (size_t)n * T1 * 3 * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
@@ -498,6 +505,8 @@ int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size
 }
 
 uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves : 0; }
+
+int32_t bn_mppi_row_pitch(const bn_mppi_t *h) { return h ? h->p.Kp : 0; }
 
 int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t *n_solves)
 {
@@ -533,6 +542,11 @@ int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise)
     if (h->d_U) bytes += 8 * K * T;                     // _perturbed_action_seqs write
     return bytes;
 }
+
+#ifdef BN_TIMING
+/* tools/ablate.py only: device buffer of >= 16 uint64 for the in-kernel cycle stamps */
+void bn_mppi_debug_set_stamps(bn_mppi_t *h, void *device_ptr) { h->p.stamps = (unsigned long long *)device_ptr; }
+#endif
 
 const char *bn_last_error(void) { return g_last_error.c_str(); }
 int bn_mppi_abi_version(void) { return BN_MPPI_ABI_VERSION; }

@@ -16,6 +16,7 @@ enum EpsMode : int { kEpsPhilox = 0, kEpsKT2 = 1, kEpsT2K = 2 };
 struct SolveParams {
     int K, T, G, B;
     int nblk;            // ceil(K / 64)
+    int Kp;              // row pitch of X and U in floats: 64 * nblk (lanes past K store into the pad)
     int WN;              // LDS window edge in cells, 0 = gather from global memory
     int reach;           // ceil(T * vmax * dt / res) + 1 cells
     int map_stride;      // G*G if every instance has its own map, 0 if shared
@@ -33,8 +34,8 @@ struct SolveParams {
     const float *goal;   // (B, 2)
     float *mean;         // (B, T, 2)   read by rollout, rewritten by finish
     const float *eps;    // per EpsMode, or nullptr
-    float *X;            // (B, T+1, 3, K)
-    float *U;            // (B, T, 2, K) or nullptr
+    float *X;            // (B, T+1, 3, Kp)
+    float *U;            // (B, T, 2, Kp) or nullptr
     float *cost;         // (B, K)
     float *part;         // (B, nblk, 2 + 2T): block max, block sum, block weighted control sums
     float *w;            // (B, K)
@@ -42,6 +43,7 @@ struct SolveParams {
     float *xstar;        // (B, T+1, 3)
     float *stats;        // (B, 2): max z, sum exp
     unsigned long long *counter;  // solves completed (Philox stream position), device resident
+    unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0
 };
 
 size_t rollout_lds_bytes(const SolveParams &p);
@@ -51,9 +53,9 @@ hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
 
 // layout conversion helpers (planner-native k-fastest <-> reference k-major)
-hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int T1, hipStream_t s);   // (T1,3,K)->(K,T1,3)
-hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int T, hipStream_t s);  // (T,2,K)->(K,T,2)
-hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int K, int T1, hipStream_t s);
+hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s);   // (T1,3,Kp)->(K,T1,3)
+hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int Kp, int T, hipStream_t s);  // (T,2,Kp)->(K,T,2)
+hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int Kp, int T1, hipStream_t s);
 hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s);
 
 }  // namespace bn

@@ -26,16 +26,46 @@ namespace {
 
 constexpr int TU = 4;   // time steps per software-pipelined chunk (noise is fetched one chunk ahead)
 
-struct Win { int wx0, wy0; };
+// Timing ablations for tools/ablate.py (never set in the shipped library): bit 0 skip stage cost,
+// 1 skip fp64 accumulation, 2 skip X stores, 3 skip control tile + control cost, 4 skip sincos,
+// 5 skip the gather, 6 skip the heading wrap.
+#ifndef BN_ABLATE
+#define BN_ABLATE 0
+#endif
+#define BN_KEEP(v) asm volatile("" ::"v"(v))
+#ifdef BN_TIMING
+#define BN_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                          \
+            p.stamps[slot] = __builtin_readcyclecounter();                                               \
+    } while (0)
+#else
+#define BN_STAMP(slot) do { } while (0)
+#endif
 
-template <bool POW2>
+// Geometry specialisations of the cell index ((p - origin) / res).floor().int()  (grid_map.py:195-209):
+//   kGeoGeneral  true division            kGeoPow2  res is a power of two: * (1/res) is bit-identical
+//   kGeoPow2Origin0  additionally origin == 0, so the subtraction is the identity
+enum Geo : int { kGeoGeneral = 0, kGeoPow2 = 1, kGeoPow2Origin0 = 2 };
+
+struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; };   // window origin (cells), as floats, edge, edge-1
+
+template <int GEO>
+__device__ __forceinline__ int raw_cell(float v, float origin, float res, float inv_res)
+{
+    const float q = (GEO == kGeoPow2Origin0) ? v * inv_res : (GEO == kGeoPow2) ? (v - origin) * inv_res : (v - origin) / res;
+    return (int)floorf(q);                    // v_cvt_i32_f32 saturates
+}
+
+template <int GEO>
 __device__ __forceinline__ Win window_origin(const SolveParams &p, float sx, float sy)
 {
-    const int cx = cell_index<POW2>(sx, p.x0, p.res, p.inv_res, p.G - 1);
-    const int cy = cell_index<POW2>(sy, p.y0, p.res, p.inv_res, p.G - 1);
+    const int cx = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    const int cy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
     Win w;
     w.wx0 = min(max(cx - p.reach, 0), p.G - p.WN);
     w.wy0 = min(max(cy - p.reach, 0), p.G - p.WN);
+    w.fx0 = (float)w.wx0; w.fy0 = (float)w.wy0; w.fwn = (float)p.WN; w.fwm1 = (float)(p.WN - 1);
     return w;
 }
 
@@ -54,36 +84,74 @@ __device__ __forceinline__ void stage_window(float *win, const float *__restrict
     }
 }
 
-template <bool POW2, bool LDSWIN>
+// Traversability at (x, y): index clamp (grid_map.py:209) then the gather.  With the LDS window the
+// two clamps (map, then window) collapse into one: the window lies inside the map, so clamping
+// i - wx0 to [0, WN-1] gives the same cell for every i (in, left of, or right of the map).
+// SAFE additionally bounds the raw index first, for a caller-supplied start state of any magnitude.
+template <int GEO, bool LDSWIN, bool SAFE>
 __device__ __forceinline__ float trav_lookup(const SolveParams &p, const float *win,
                                              const float *__restrict__ map, const Win w, float x, float y)
 {
-    const int ix = cell_index<POW2>(x, p.x0, p.res, p.inv_res, p.G - 1);
-    const int iy = cell_index<POW2>(y, p.y0, p.res, p.inv_res, p.G - 1);
+    int ix = raw_cell<GEO>(x, p.x0, p.res, p.inv_res);
+    int iy = raw_cell<GEO>(y, p.y0, p.res, p.inv_res);
     if (LDSWIN) {
-        const int li = min(max(ix - w.wx0, 0), p.WN - 1);
-        const int lj = min(max(iy - w.wy0, 0), p.WN - 1);
-        return win[lj * p.WN + li];
+        if (SAFE) { ix = clampi(ix, 0, p.G - 1); iy = clampi(iy, 0, p.G - 1); }
+        const int li = clampi(ix - w.wx0, 0, p.WN - 1);
+        const int lj = clampi(iy - w.wy0, 0, p.WN - 1);
+        return win[(int)__umul24((unsigned)lj, (unsigned)p.WN) + li];
     }
+    ix = clampi(ix, 0, p.G - 1);
+    iy = clampi(iy, 0, p.G - 1);
     return 1.0f - clampf(map[(size_t)iy * p.G + ix], 0.0f, 1.0f);
 }
 
-// One UnicycleModel.transit (robot_model.py:59-100).  (x,y,th) enter as the
-// clamped state t and leave as the clamped/wrapped state t+1; (xn,yn,tn) is what
-// the reference leaves in slot t (un-clamped, un-wrapped).  `trav` is the
-// traversability at (x,y) on entry.
-__device__ __forceinline__ void transit_step(const SolveParams &p, float trav, float u0, float u1,
-                                             float &x, float &y, float &th, float &xn, float &yn, float &tn)
+// In-loop gather: (x, y) already lies inside the map limits.  The window-relative cell is computed in
+// the float domain: q = (x - origin)/res as the reference rounds it, then q - wx0 (exact: an integer
+// no larger than q is subtracted), floor, clamp to the window, row * WN + col (exact small integers),
+// one conversion.  Same cell as trav_lookup<..., false> for every in-limits position.
+template <int GEO>
+__device__ __forceinline__ float trav_window(const SolveParams &p, const float *win, const Win w, float x, float y)
 {
-    float sn, cs;
-    sincos_spec(th, sn, cs);
-    const float tv = trav * u0;          // u0,u1 already lie in [u_min,u_max]: the re-clamp of :82-83 is the identity
-    xn = x + (tv * cs) * p.dt;           // :86
-    yn = y + (tv * sn) * p.dt;           // :87
-    tn = th + (trav * u1) * p.dt;        // :88
-    x = clampf(xn, p.x0, p.x_hi);        // :93
-    y = clampf(yn, p.y0, p.y_hi);        // :94
-    th = wrap_angle(tn);                 // :90
+    float qx, qy;
+    if (GEO == kGeoPow2Origin0) {
+        qx = __builtin_fmaf(x, p.inv_res, -w.fx0);
+        qy = __builtin_fmaf(y, p.inv_res, -w.fy0);
+    } else if (GEO == kGeoPow2) {
+        qx = __builtin_fmaf(x - p.x0, p.inv_res, -w.fx0);
+        qy = __builtin_fmaf(y - p.y0, p.inv_res, -w.fy0);
+    } else {
+        qx = (x - p.x0) / p.res - w.fx0;
+        qy = (y - p.y0) / p.res - w.fy0;
+    }
+    const float li = clampf(floorf(qx), 0.0f, w.fwm1);
+    const float lj = clampf(floorf(qy), 0.0f, w.fwm1);
+    return win[(int)__builtin_fmaf(lj, w.fwn, li)];
+}
+
+// Per-rollout recurrence state: the clamped/wrapped state t, its traversability, sin/cos of its heading.
+struct Chain { float x, y, th, sn, cs, trav; };
+
+// One UnicycleModel.transit (robot_model.py:59-100) plus the gather for the next step.
+// (xn, yn, tn) is what the reference leaves in slot t (un-clamped, un-wrapped); the chain
+// advances to the clamped/wrapped state t+1.  The two dependent strands -- heading (wrap, sincos) and
+// position (clamp, cell index, LDS gather) -- are independent after `trav` and overlap in issue.
+// u0, u1 already lie in [u_min, u_max]: the re-clamp of robot_model.py:82-83 is the identity.
+template <int GEO, bool LDSWIN, bool FIRST>
+__device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
+                                           const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn)
+{
+    const float tv = c.trav * u0;
+    tn = c.th + (c.trav * u1) * p.dt;                                  // :88
+    xn = c.x + (tv * c.cs) * p.dt;                                     // :86
+    yn = c.y + (tv * c.sn) * p.dt;                                     // :87
+    if (BN_ABLATE & 64) c.th = tn; else
+    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);               // :90
+    c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
+    c.y = clampf(yn, p.y0, p.y_hi);                                    // :94
+    if (BN_ABLATE & 16) { c.sn = c.th * 0.5f; c.cs = 1.0f - c.th; } else
+    sincos_spec(c.th, c.sn, c.cs);
+    if (BN_ABLATE & 32) { c.trav = 0.5f + 0.001f * c.x; } else
+    c.trav = LDSWIN ? trav_window<GEO>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
 }
 
 __device__ __forceinline__ float wave_max(float v)
@@ -99,6 +167,7 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Noise of steps t0 .. t0+TU-1 (t0 odd: step 0 is peeled) for rollout kk of instance b.
 template <int EPS>
 __device__ __forceinline__ void load_eps_chunk(const SolveParams &p, const float *__restrict__ eps, int b, int kk,
                                                int t0, uint64_t solve, float (&e)[TU][2])
@@ -107,7 +176,7 @@ __device__ __forceinline__ void load_eps_chunk(const SolveParams &p, const float
 #pragma unroll
         for (int i = 0; i < TU / 2; ++i) {
             float z[4];
-            philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(t0 / 2 + i), z);
+            philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)kk, (uint32_t)((t0 + 1) / 2 + i), z);
             e[2 * i][0] = z[0]; e[2 * i][1] = z[1];
             e[2 * i + 1][0] = z[2]; e[2 * i + 1][1] = z[3];
         }
@@ -122,10 +191,28 @@ __device__ __forceinline__ void load_eps_chunk(const SolveParams &p, const float
 #pragma unroll
         for (int i = 0; i < TU; ++i) {
             const int t = min(t0 + i, p.T - 1);
-            const size_t row = ((size_t)b * p.T + t) * 2;
-            e[i][0] = eps[row * p.K + kk];
-            e[i][1] = eps[(row + 1) * p.K + kk];
+            const float *row = eps + ((size_t)b * p.T + t) * 2 * p.K;
+            e[i][0] = row[kk];
+            e[i][1] = row[p.K + kk];
         }
+    }
+}
+
+template <int EPS>
+__device__ __forceinline__ void load_eps_step0(const SolveParams &p, const float *__restrict__ eps, int b, int kk,
+                                               uint64_t solve, float (&e)[2])
+{
+    if (EPS == kEpsPhilox) {
+        float z[4];
+        philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)kk, 0u, z);
+        e[0] = z[2]; e[1] = z[3];
+    } else if (EPS == kEpsKT2) {
+        const float2 v = *reinterpret_cast<const float2 *>(eps + ((size_t)b * p.K + kk) * p.T * 2);
+        e[0] = v.x; e[1] = v.y;
+    } else {
+        const float *row = eps + (size_t)b * p.T * 2 * p.K;
+        e[0] = row[kk];
+        e[1] = row[p.K + kk];
     }
 }
 
@@ -133,7 +220,7 @@ __device__ __forceinline__ void load_eps_chunk(const SolveParams &p, const float
 // Rollout + cost kernel.  grid = (ceil(K/64), B), block = 64 (one wavefront).
 // LDS: [ window WN*WN | mean 2T | mean*inv_var 2T | control tile 2T x 65 | e 64 ]
 // ------------------------------------------------------------------------------
-template <int EPS, bool POW2, bool LDSWIN>
+template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
 __global__ __launch_bounds__(kRolloutsPerBlock) void rollout_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -155,13 +242,16 @@ __global__ __launch_bounds__(kRolloutsPerBlock) void rollout_kernel(const SolveP
     const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
     const uint64_t solve = (EPS == kEpsPhilox) ? (uint64_t)*p.counter : 0;
+    BN_STAMP(0);
 
+    float e0[2];
     float ecur[TU][2], enext[TU][2];
-    load_eps_chunk<EPS>(p, eps, b, kk, 0, solve, ecur);
+    load_eps_step0<EPS>(p, eps, b, kk, solve, e0);
+    load_eps_chunk<EPS>(p, eps, b, kk, 1, solve, ecur);
 
-    Win w{0, 0};
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN) {
-        w = window_origin<POW2>(p, sx, sy);
+        w = window_origin<GEO>(p, sx, sy);
         stage_window(win, map, w, p.WN, p.G, lane, kRolloutsPerBlock);
     }
     for (int j = lane; j < 2 * T; j += kRolloutsPerBlock) {
@@ -170,67 +260,90 @@ __global__ __launch_bounds__(kRolloutsPerBlock) void rollout_kernel(const SolveP
         mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);      // mean[t] @ inv_cov (diagonal), mppi.py:179-180
     }
     __syncthreads();
+    BN_STAMP(1);
 
-    float x = sx, y = sy, th = sth;                   // mppi.py:160
-    float trav = trav_lookup<POW2, LDSWIN>(p, win, map, w, x, y);
+    Chain c;
+    c.x = sx; c.y = sy; c.th = sth;                   // mppi.py:160
+    sincos_spec(c.th, c.sn, c.cs);
+    c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
     double Sd = 0.0, Ad = 0.0;                        // fp64 accumulation of the fp32 terms (Arithmetic spec)
-    float *Xk = p.X + (size_t)b * (T + 1) * 3 * K + k;
-    float *Uk = p.U ? p.U + (size_t)b * T * 2 * K + k : nullptr;
+    float Sf = 0.0f, Af = 0.0f;                       // (ablation builds only)
+    // Rows of X and U are pitched to Kp = 64 * nblk floats, so every lane stores unconditionally
+    // (lanes past K write into the pad) and the step body stays one basic block.
+    const size_t Kp = (size_t)p.Kp;
+    float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
+    float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
 
-    for (int t0 = 0; t0 < T; t0 += TU) {
-        if (t0 + TU < T) load_eps_chunk<EPS>(p, eps, b, kk, t0 + TU, solve, enext);
+    // One time step for this lane's rollout: sample the control, advance the chain, emit slot t,
+    // accumulate the control cost and the stage cost of the aliased slot.
+#define BN_STEP(FIRST, t, eps0, eps1)                                                                          \
+    do {                                                                                                       \
+        const float m0 = ml[2 * (t)], m1 = ml[2 * (t) + 1];                                                    \
+        const float u0 = clampf(m0 + p.sigma0 * (eps0), p.umin0, p.umax0);   /* mppi.py:152-157 */             \
+        const float u1 = clampf(m1 + p.sigma1 * (eps1), p.umin1, p.umax1);                                     \
+        float xn, yn, tn;                                                                                      \
+        chain_step<GEO, LDSWIN, FIRST>(p, win, map, w, c, u0, u1, xn, yn, tn);                                 \
+        if (!(BN_ABLATE & 8)) {                                                                                \
+        Ul[(2 * (t)) * kUPad + lane] = u0;                                                                     \
+        Ul[(2 * (t) + 1) * kUPad + lane] = u1;                                                                 \
+        }                                                                                                      \
+        if (!(BN_ABLATE & 4)) {                                                                                \
+        float *Xt = Xb + (size_t)(3 * (t)) * Kp;         /* slot t keeps the un-clamped state (aliasing) */     \
+        Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                              \
+        } else { BN_KEEP(xn); BN_KEEP(yn); BN_KEEP(tn); }                                                      \
+        if (STORE_U) { float *Ut = Ub + (size_t)(2 * (t)) * Kp; Ut[0] = u0; Ut[Kp] = u1; }                     \
+        if (!(BN_ABLATE & 8)) {                                                                                \
+        const float a = mv[2 * (t)] * u0 + mv[2 * (t) + 1] * u1;            /* mppi.py:178-182 */             \
+        if (BN_ABLATE & 2) Af += p.lambda_ * a; else                                                           \
+        Ad += (double)(p.lambda_ * a);                                                                         \
+        }                                                                                                      \
+        /* the cell of the un-clamped slot equals the cell of the clamped state (index clamp,               */ \
+        /* grid_map.py:209), so c.trav serves stage cost t and transit t+1                                  */ \
+        if (!(BN_ABLATE & 1)) {                                                                                \
+        const float dx = xn - gx, dy = yn - gy;                                                                \
+        const float sc = sqrtf(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f);   /* objectives.py:47-53 */ \
+        if (BN_ABLATE & 2) Sf += sc; else                                                                      \
+        Sd += (double)sc;                                                                                      \
+        }                                                                                                      \
+    } while (0)
+
+    BN_STEP(true, 0, e0[0], e0[1]);
+    BN_STAMP(2);
+    int t0 = 1;
+    for (; t0 + TU <= T; t0 += TU) {
+        load_eps_chunk<EPS>(p, eps, b, kk, t0 + TU, solve, enext);      // indices clamp at T-1: always in bounds
 #pragma unroll
-        for (int i = 0; i < TU; ++i) {
-            const int t = t0 + i;
-            if (t < T) {
-                const float m0 = ml[2 * t], m1 = ml[2 * t + 1];
-                // sampling: clamp(mean + sigma*eps, u_min, u_max)   mppi.py:152-157
-                const float u0 = clampf(m0 + p.sigma0 * ecur[i][0], p.umin0, p.umax0);
-                const float u1 = clampf(m1 + p.sigma1 * ecur[i][1], p.umin1, p.umax1);
-                Ul[(2 * t) * kUPad + lane] = u0;
-                Ul[(2 * t + 1) * kUPad + lane] = u1;
-                if (Uk && active) {
-                    Uk[(size_t)(2 * t) * K] = u0;
-                    Uk[(size_t)(2 * t + 1) * K] = u1;
-                }
-                // control cost  mean[t] @ inv_cov @ u   mppi.py:178-182
-                const float a = mv[2 * t] * u0 + mv[2 * t + 1] * u1;
-                Ad += (double)(p.lambda_ * a);
-                float xn, yn, tn;
-                transit_step(p, trav, u0, u1, x, y, th, xn, yn, tn);
-                if (active) {                          // slot t keeps the un-clamped state (aliasing)
-                    Xk[(size_t)(3 * t + 0) * K] = xn;
-                    Xk[(size_t)(3 * t + 1) * K] = yn;
-                    Xk[(size_t)(3 * t + 2) * K] = tn;
-                }
-                // The cell of the un-clamped slot equals the cell of the clamped state
-                // (index clamp, grid_map.py:209), so one gather serves stage cost t and transit t+1.
-                trav = trav_lookup<POW2, LDSWIN>(p, win, map, w, x, y);
-                const float dx = xn - gx, dy = yn - gy;
-                const float s = sqrtf(dx * dx + dy * dy) + (trav <= p.thr ? 1.0e4f : 0.0f);   // objectives.py:47-53
-                Sd += (double)s;
-            }
-        }
+        for (int i = 0; i < TU; ++i) BN_STEP(false, t0 + i, ecur[i][0], ecur[i][1]);
 #pragma unroll
         for (int i = 0; i < TU; ++i) { ecur[i][0] = enext[i][0]; ecur[i][1] = enext[i][1]; }
     }
-    if (active) {                                      // slot T: clamped / wrapped state
-        Xk[(size_t)(3 * T + 0) * K] = x;
-        Xk[(size_t)(3 * T + 1) * K] = y;
-        Xk[(size_t)(3 * T + 2) * K] = th;
+#pragma unroll
+    for (int i = 0; i < TU - 1; ++i)
+        if (t0 + i < T) BN_STEP(false, t0 + i, ecur[i][0], ecur[i][1]);
+#undef BN_STEP
+    BN_STAMP(3);
+
+    {                                                  // slot T: clamped / wrapped state
+        float *Xt = Xb + (size_t)(3 * T) * Kp;
+        Xt[0] = c.x; Xt[Kp] = c.y; Xt[2 * Kp] = c.th;
     }
-    const float dxT = x - gx, dyT = y - gy;
-    const float term = sqrtf(dxT * dxT + dyT * dyT) + (trav <= p.thr ? 1.0e4f : 0.0f);        // mppi.py:184
-    const float c = ((float)Sd + term) + (float)Ad;                                            // mppi.py:186-190
-    if (active) p.cost[(size_t)b * K + k] = c;
+    const float dxT = c.x - gx, dyT = c.y - gy;
+    const float term = sqrtf(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);     // mppi.py:184
+#if BN_ABLATE
+    const float cost = (((float)Sd + Sf) + term) + ((float)Ad + Af);
+#else
+    const float cost = ((float)Sd + term) + (float)Ad;                                         // mppi.py:186-190
+#endif
+    if (active) p.cost[(size_t)b * K + k] = cost;
 
     // block-local softmin statistics   mppi.py:193-199
-    const float z = active ? (-c) / p.lambda_ : -INFINITY;
+    const float z = active ? (-cost) / p.lambda_ : -INFINITY;
     const float zmax = wave_max(z);
     const float e = active ? expf(z - zmax) : 0.0f;
     const float esum = wave_sum(e);
     el[lane] = e;
     __syncthreads();
+    BN_STAMP(4);
     float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
     for (int j = lane; j < 2 * T; j += kRolloutsPerBlock) {
         const float *col = Ul + j * kUPad;
@@ -240,6 +353,7 @@ __global__ __launch_bounds__(kRolloutsPerBlock) void rollout_kernel(const SolveP
         part[2 + j] = acc;
     }
     if (lane == 0) { part[0] = zmax; part[1] = esum; }
+    BN_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------
@@ -258,7 +372,7 @@ __device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool
     return r;
 }
 
-template <bool POW2, bool LDSWIN>
+template <int GEO, bool LDSWIN>
 __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -273,12 +387,14 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParam
     const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
     const float *part = p.part + (size_t)b * nblk * PS;
     const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    BN_STAMP(8);
 
-    Win w{0, 0};
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN) {
-        w = window_origin<POW2>(p, sx, sy);
+        w = window_origin<GEO>(p, sx, sy);
         stage_window(win, map, w, p.WN, p.G, tid, kFinishThreads);
     }
+    BN_STAMP(9);
 
     float m = -INFINITY;
     for (int i = tid; i < nblk; i += kFinishThreads) m = fmaxf(m, part[(size_t)i * PS]);
@@ -305,19 +421,24 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParam
         if (b == 0) *p.counter += 1ull;
     }
     __syncthreads();
+    BN_STAMP(10);
 
     if (tid == 0) {
         // optimal_state_seq: batch-1 rollout of U* with the same aliasing (mppi.py:202-214)
-        float x = sx, y = sy, th = sth;
-        float trav = trav_lookup<POW2, LDSWIN>(p, win, map, w, x, y);
+        Chain c;
+        c.x = sx; c.y = sy; c.th = sth;
+        sincos_spec(c.th, c.sn, c.cs);
+        c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
         float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
-        for (int t = 0; t < T; ++t) {
-            float xn, yn, tn;
-            transit_step(p, trav, us[2 * t], us[2 * t + 1], x, y, th, xn, yn, tn);
+        float xn, yn, tn;
+        chain_step<GEO, LDSWIN, true>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
+        Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
+        for (int t = 1; t < T; ++t) {
+            chain_step<GEO, LDSWIN, false>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn);
             Xs[3 * t + 0] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
-            trav = trav_lookup<POW2, LDSWIN>(p, win, map, w, x, y);
         }
-        Xs[3 * T + 0] = x; Xs[3 * T + 1] = y; Xs[3 * T + 2] = th;
+        Xs[3 * T + 0] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
+        BN_STAMP(11);
     } else if (tid >= 64) {
         // _weights = softmax(-costs / lambda)   mppi.py:193
         const float *cost = p.cost + (size_t)b * K;
@@ -328,36 +449,38 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParam
 }
 
 // ---- layout helpers -----------------------------------------------------------
-__global__ void soa_to_aos_kernel(const float *__restrict__ in, float *__restrict__ out, int K, int R)
-{   // in (R, K) -> out (K, R)
+__global__ void soa_to_aos_kernel(const float *__restrict__ in, float *__restrict__ out, int K, int Kp, int R)
+{   // in (R, Kp pitch) -> out (K, R)
     const size_t n = (size_t)K * R;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t k = i / R, r = i - k * R;
-        out[i] = in[r * K + k];
+        out[i] = in[r * Kp + k];
     }
 }
 
 __global__ void gather_states_kernel(const float *__restrict__ X, const int *__restrict__ idx,
-                                     float *__restrict__ out, int n, int K, int R)
-{   // out (n, R) = X (R, K)[:, idx]
+                                     float *__restrict__ out, int n, int Kp, int R)
+{   // out (n, R) = X (R, Kp pitch)[:, idx]
     const size_t tot = (size_t)n * R;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         const size_t q = i / R, r = i - q * R;
-        out[i] = X[r * K + idx[q]];
+        out[i] = X[r * Kp + idx[q]];
     }
 }
 
 __global__ void philox_noise_kernel(float *__restrict__ eps, uint64_t seed, uint64_t solve, int b, int K, int T)
 {   // eps (K, T, 2) of one instance, exactly the stream rollout_kernel<kEpsPhilox> consumes
-    const int npair = (T + 1) / 2;
+    const int npair = T / 2 + 1;                    // pair p = steps (2p-1, 2p)
     const size_t tot = (size_t)K * npair;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i / npair), tp = (int)(i - (size_t)k * npair);
+        const int k = (int)(i / npair), pr = (int)(i - (size_t)k * npair);
         float z[4];
-        philox_eps_pair(seed, solve, (uint32_t)b, (uint32_t)k, (uint32_t)tp, z);
-        const int t = 2 * tp;
-        eps[((size_t)k * T + t) * 2 + 0] = z[0];
-        eps[((size_t)k * T + t) * 2 + 1] = z[1];
+        philox_eps_pair(seed, solve, (uint32_t)b, (uint32_t)k, (uint32_t)pr, z);
+        const int t = 2 * pr - 1;
+        if (t >= 0) {
+            eps[((size_t)k * T + t) * 2 + 0] = z[0];
+            eps[((size_t)k * T + t) * 2 + 1] = z[1];
+        }
         if (t + 1 < T) {
             eps[((size_t)k * T + t + 1) * 2 + 0] = z[2];
             eps[((size_t)k * T + t + 1) * 2 + 1] = z[3];
@@ -372,31 +495,46 @@ hipError_t ensure_lds(Kern kern, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int EPS, bool POW2, bool LDSWIN>
-hipError_t launch_rollout_t(const SolveParams &p, hipStream_t s)
+int geo_of(const SolveParams &p)
+{
+    if (!p.pow2) return kGeoGeneral;
+    return (p.x0 == 0.0f && p.y0 == 0.0f) ? kGeoPow2Origin0 : kGeoPow2;
+}
+
+template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
+hipError_t launch_rollout_u(const SolveParams &p, hipStream_t s)
 {
     const size_t lds = rollout_lds_bytes(p);
-    hipError_t e = ensure_lds(rollout_kernel<EPS, POW2, LDSWIN>, lds);
+    hipError_t e = ensure_lds(rollout_kernel<EPS, GEO, LDSWIN, STORE_U>, lds);
     if (e != hipSuccess) return e;
-    rollout_kernel<EPS, POW2, LDSWIN><<<dim3(p.nblk, p.B), dim3(kRolloutsPerBlock), lds, s>>>(p);
+    rollout_kernel<EPS, GEO, LDSWIN, STORE_U><<<dim3(p.nblk, p.B), dim3(kRolloutsPerBlock), lds, s>>>(p);
     return hipGetLastError();
+}
+
+template <int EPS, int GEO, bool LDSWIN>
+hipError_t launch_rollout_t(const SolveParams &p, hipStream_t s)
+{
+    return p.U ? launch_rollout_u<EPS, GEO, LDSWIN, true>(p, s) : launch_rollout_u<EPS, GEO, LDSWIN, false>(p, s);
 }
 
 template <int EPS>
 hipError_t launch_rollout_e(const SolveParams &p, hipStream_t s)
 {
     const bool win = p.WN > 0;
-    if (p.pow2) return win ? launch_rollout_t<EPS, true, true>(p, s) : launch_rollout_t<EPS, true, false>(p, s);
-    return win ? launch_rollout_t<EPS, false, true>(p, s) : launch_rollout_t<EPS, false, false>(p, s);
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: return win ? launch_rollout_t<EPS, kGeoPow2Origin0, true>(p, s) : launch_rollout_t<EPS, kGeoPow2Origin0, false>(p, s);
+    case kGeoPow2: return win ? launch_rollout_t<EPS, kGeoPow2, true>(p, s) : launch_rollout_t<EPS, kGeoPow2, false>(p, s);
+    default: return win ? launch_rollout_t<EPS, kGeoGeneral, true>(p, s) : launch_rollout_t<EPS, kGeoGeneral, false>(p, s);
+    }
 }
 
-template <bool POW2, bool LDSWIN>
+template <int GEO, bool LDSWIN>
 hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
 {
     const size_t lds = finish_lds_bytes(p);
-    hipError_t e = ensure_lds(finish_kernel<POW2, LDSWIN>, lds);
+    hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN>, lds);
     if (e != hipSuccess) return e;
-    finish_kernel<POW2, LDSWIN><<<dim3(p.B), dim3(kFinishThreads), lds, s>>>(p);
+    finish_kernel<GEO, LDSWIN><<<dim3(p.B), dim3(kFinishThreads), lds, s>>>(p);
     return hipGetLastError();
 }
 
@@ -424,33 +562,36 @@ hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)
 hipError_t launch_finish(const SolveParams &p, hipStream_t s)
 {
     const bool win = p.WN > 0;
-    if (p.pow2) return win ? launch_finish_t<true, true>(p, s) : launch_finish_t<true, false>(p, s);
-    return win ? launch_finish_t<false, true>(p, s) : launch_finish_t<false, false>(p, s);
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: return win ? launch_finish_t<kGeoPow2Origin0, true>(p, s) : launch_finish_t<kGeoPow2Origin0, false>(p, s);
+    case kGeoPow2: return win ? launch_finish_t<kGeoPow2, true>(p, s) : launch_finish_t<kGeoPow2, false>(p, s);
+    default: return win ? launch_finish_t<kGeoGeneral, true>(p, s) : launch_finish_t<kGeoGeneral, false>(p, s);
+    }
 }
 
 static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256); }
 
-hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int T1, hipStream_t s)
+hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s)
 {
-    soa_to_aos_kernel<<<grid_for((size_t)K * T1 * 3), 256, 0, s>>>(X_soa, X_aos, K, T1 * 3);
+    soa_to_aos_kernel<<<grid_for((size_t)K * T1 * 3), 256, 0, s>>>(X_soa, X_aos, K, Kp, T1 * 3);
     return hipGetLastError();
 }
 
-hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int T, hipStream_t s)
+hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int Kp, int T, hipStream_t s)
 {
-    soa_to_aos_kernel<<<grid_for((size_t)K * T * 2), 256, 0, s>>>(U_soa, U_aos, K, T * 2);
+    soa_to_aos_kernel<<<grid_for((size_t)K * T * 2), 256, 0, s>>>(U_soa, U_aos, K, Kp, T * 2);
     return hipGetLastError();
 }
 
-hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int K, int T1, hipStream_t s)
+hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int Kp, int T1, hipStream_t s)
 {
-    gather_states_kernel<<<grid_for((size_t)n * T1 * 3), 256, 0, s>>>(X_soa, idx, out, n, K, T1 * 3);
+    gather_states_kernel<<<grid_for((size_t)n * T1 * 3), 256, 0, s>>>(X_soa, idx, out, n, Kp, T1 * 3);
     return hipGetLastError();
 }
 
 hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s)
 {
-    philox_noise_kernel<<<grid_for((size_t)K * ((T + 1) / 2)), 256, 0, s>>>(eps_kt2, seed, solve, b, K, T);
+    philox_noise_kernel<<<grid_for((size_t)K * (T / 2 + 1)), 256, 0, s>>>(eps_kt2, seed, solve, b, K, T);
     return hipGetLastError();
 }
 

@@ -132,10 +132,11 @@ class MPPI(nn.Module):
         self.set_goal(inp["goal"])
 
         K, T = num_samples, horizon
-        self._buf_X = self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, K))
+        Kp = int(lib.bn_mppi_row_pitch(self._handle))        # rows are pitched to 64*ceil(K/64) floats
+        self._buf_X = self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, Kp))[:, :, :K]
         self._buf_w = self._wrap(_capi.BN_BUF_WEIGHTS, (K,))
         self._buf_cost = self._wrap(_capi.BN_BUF_COSTS, (K,))
-        self._buf_U = self._wrap(_capi.BN_BUF_CONTROLS, (T, 2, K)) if store_controls else None
+        self._buf_U = self._wrap(_capi.BN_BUF_CONTROLS, (T, 2, Kp))[:, :, :K] if store_controls else None
         self._buf_ustar = self._wrap(_capi.BN_BUF_USTAR, (T, 2))
         self._buf_xstar = self._wrap(_capi.BN_BUF_XSTAR, (1, T + 1, 3))
         self._buf_mean = self._wrap(_capi.BN_BUF_MEAN, (T, 2))

@@ -52,10 +52,11 @@ typedef enum bn_mem_kind { BN_MEM_HOST = 0, BN_MEM_DEVICE = 1 } bn_mem_kind;
 
 /* Device buffers a caller may map without a copy (bn_mppi_device_buffer). */
 typedef enum bn_buffer_id {
-    BN_BUF_STATES = 0,    /* (B,T+1,3,K)  _state_seq_batch, planner-native layout (k fastest)   */
+    BN_BUF_STATES = 0,    /* (B,T+1,3,Kp) _state_seq_batch, planner-native layout: k fastest, rows pitched to
+                             Kp = 64*ceil(K/64) floats (bn_mppi_row_pitch)                          */
     BN_BUF_WEIGHTS = 1,   /* (B,K)        _weights                                             */
     BN_BUF_COSTS = 2,     /* (B,K)        per-rollout total cost                               */
-    BN_BUF_CONTROLS = 3,  /* (B,T,2,K)    _perturbed_action_seqs (only with BN_FLAG_STORE_CONTROLS) */
+    BN_BUF_CONTROLS = 3,  /* (B,T,2,Kp)   _perturbed_action_seqs (only with BN_FLAG_STORE_CONTROLS) */
     BN_BUF_USTAR = 4,     /* (B,T,2)      optimal_action_seq                                   */
     BN_BUF_XSTAR = 5,     /* (B,T+1,3)    optimal_state_seq                                    */
     BN_BUF_MEAN = 6,      /* (B,T,2)      _previous_action_seq                                 */
@@ -163,6 +164,9 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
 
 /* Zero-copy access to a library-owned device buffer (layouts in bn_buffer_id). */
 int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size_t *bytes);
+
+/* Row pitch Kp (in floats) of BN_BUF_STATES / BN_BUF_CONTROLS. */
+int32_t bn_mppi_row_pitch(const bn_mppi_t *h);
 
 /* Number of solves enqueued so far (the Philox stream position). */
 uint64_t bn_mppi_solve_count(const bn_mppi_t *h);
