@@ -64,7 +64,8 @@ def make_planner(inst, dev, B=1, profile=False, shared_map=True):
 
 
 def timed_solves(pl, state_dev, eps_ring, kind, steps, sync):
-    """Enqueue `steps` dependent solves; returns wall seconds between the two syncs."""
+    """Enqueue `steps` dependent solves (software-pipelined: one launch each), then the tail of the last
+    one; returns wall seconds between the two syncs.  Every solve's U*, X* and weights are written."""
     sync()
     t0 = time.perf_counter()
     if eps_ring is None:
@@ -74,31 +75,60 @@ def timed_solves(pl, state_dev, eps_ring, kind, steps, sync):
         n = len(eps_ring)
         for i in range(steps):
             pl.solve_async_device(state_dev.data_ptr(), eps_ring[i % n].data_ptr(), kind)
+    pl.flush()
     sync()
     return time.perf_counter() - t0
 
 
+def settle(make, state_dev, eps_ring, kind, warmup, sync_local, tries=3):
+    """Untimed: build the planner, run the warm-up steps, and make sure the queue is not in the
+    rare slow-dispatch state seen on some boxes (milliseconds between back-to-back launches): if a
+    100-step probe is >5x slower than the best probe seen, rebuild the handle and try again."""
+    best = None
+    for _ in range(tries):
+        pl = make()
+        timed_solves(pl, state_dev, eps_ring, kind, max(warmup, 1), sync_local)
+        probes = [timed_solves(pl, state_dev, eps_ring, kind, 100, sync_local) / 100 for _ in range(3)]
+        p = min(probes)
+        best = p if best is None else min(best, p)
+        if p <= 5 * best and p < 2e-3:
+            return pl
+        pl.close()
+    return make()
+
+
 def cpu_baseline(inst, seconds):
-    """The reference's CPU path, as ported in oracle/torch_port.py, on this box's host cores."""
+    """The reference's CPU path, as ported in oracle/torch_port.py, on this box's host cores.
+    The path is dispatch-bound (~19k ATen calls per solve), so it is timed with 1 thread and with
+    torch's default thread count and the faster of the two is reported."""
     from oracle import torch_port as TP
     pb = TP.Problem(risk=inst.risk, goal=inst.goal, grid_size=G, resolution=RES, x_limits=(0.0, G * RES),
                     y_limits=(0.0, G * RES), sigmas=torch.tensor([0.5, 0.5]), lambda_=0.5, stuck_threshold=0.3,
                     u_min=torch.tensor([0.0, -1.0]), u_max=torch.tensor([1.0, 1.0]))
-    torch.manual_seed(42)
-    mean = torch.zeros(T, 2)
-    for _ in range(3):
-        mean = TP.solve(pb, inst.start, mean, K=K)["Ustar"]
-    n, t0 = 0, time.perf_counter()
-    while True:
-        mean = TP.solve(pb, inst.start, mean, K=K)["Ustar"]      # warm-started chain, noise drawn per solve
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 2000:
-            break
-    out = {"value": n / el, "unit": "solves/s", "cores": torch.get_num_threads(), "kind": "port",
+    default_threads = torch.get_num_threads()
+    runs = {}
+    for threads in sorted({1, default_threads}):
+        torch.set_num_threads(threads)
+        torch.manual_seed(42)
+        mean = torch.zeros(T, 2)
+        for _ in range(3):
+            mean = TP.solve(pb, inst.start, mean, K=K)["Ustar"]
+        n, t0 = 0, time.perf_counter()
+        while True:
+            mean = TP.solve(pb, inst.start, mean, K=K)["Ustar"]      # warm-started chain, noise drawn per solve
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds / 2 or n >= 2000:
+                break
+        runs[threads] = (n / el, n, el)
+    torch.set_num_threads(default_threads)
+    best = max(runs, key=lambda k_: runs[k_][0])
+    rate, n, el = runs[best]
+    out = {"value": rate, "unit": "solves/s", "cores": best, "kind": "port",
            "sample": f"{n} warm-started solves of the same workload (K={K}, T={T}, {G}x{G} map) in {el:.1f} s, "
                      f"PyTorch-CPU port of mppi.py:130-219 (oracle/torch_port.py), torch {torch.__version__}, "
-                     f"{os.cpu_count()} host cpus"}
+                     f"{os.cpu_count()} host cpus",
+           "by_threads": {str(k_): v[0] for k_, v in runs.items()}}
     # the scalar C oracle on one core, for scale (a stronger CPU implementation than the reference's)
     try:
         from oracle import oracle as O
@@ -144,9 +174,13 @@ def main():
     else:
         eps_ring, kind = None, _capi.BN_NOISE_PHILOX
 
+    # host-side instance generation for the batched leg happens before any timing (no idle gap later)
+    batched_insts = None
+    if rank == 0 and world == 1 and not a.no_batched:
+        batched_insts = [synth.make_instance(G, seed=s, resolution=RES, jitter=True) for s in range(a.batched_instances)]
+
     # ---- headline: dependent solves of one instance per GPU -------------------------------------
-    pl = make_planner(inst, local)
-    timed_solves(pl, state_dev, eps_ring, kind, a.warmup, sync)
+    pl = settle(lambda: make_planner(inst, local), state_dev, eps_ring, kind, a.warmup, torch.cuda.synchronize)
     elapsed = timed_solves(pl, state_dev, eps_ring, kind, a.steps, sync)
     if dist is not None:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -159,8 +193,8 @@ def main():
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch, same K steps -------
-        plp = make_planner(inst, local, profile=True)
-        timed_solves(plp, state_dev, eps_ring, kind, min(a.warmup, 50), torch.cuda.synchronize)
+        plp = settle(lambda: make_planner(inst, local, profile=True), state_dev, eps_ring, kind, min(a.warmup, 50),
+                     torch.cuda.synchronize)
         plp.kernel_ms()
         el_prof = timed_solves(plp, state_dev, eps_ring, kind, a.steps, torch.cuda.synchronize)
         r_ms, f_ms, n_prof = plp.kernel_ms()
@@ -185,7 +219,9 @@ def main():
                        "parallelism": f"instance sharding x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bn::rollout_kernel", "kernel_ms": r_ms, "finish_kernel_ms": f_ms,
+                         "kernel": "bn::rollout_kernel (4 role-specialised waves per 64 rollouts; in the pipelined "
+                                   "mode it also carries the previous solve's merge + tail workgroup)",
+                         "kernel_ms": r_ms, "finish_kernel_ms": f_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_prof,
                          "ms_per_step_with_events": el_prof / a.steps * 1e3,
                          "note": "single-instance solve is a 2xT-step dependent chain: latency-bound, see DESIGN.md"},
@@ -193,19 +229,22 @@ def main():
         # ---- batched: 64 instances per launch on this GPU (HBM-relevant regime) -------------------
         if not a.no_batched and world == 1:
             B = a.batched_instances
-            insts = [synth.make_instance(G, seed=s, resolution=RES, jitter=True) for s in range(B)]
-            plb = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=local,
-                             profile=True, stream=torch.cuda.current_stream().cuda_stream)
-            for b, it in enumerate(insts):
-                plb.set_map(it.risk.numpy(), b)
-                plb.set_goal(it.goal.numpy(), b)
+            insts = batched_insts
+
+            def make_batched():
+                plb_ = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=local,
+                                  profile=True, stream=torch.cuda.current_stream().cuda_stream)
+                for b, it in enumerate(insts):
+                    plb_.set_map(it.risk.numpy(), b)
+                    plb_.set_goal(it.goal.numpy(), b)
+                return plb_
             states = torch.stack([it.start for it in insts]).cuda()
             if a.noise == "injected":
                 ring = [torch.randn(B, T, 2, K, device="cuda") for _ in range(2)]
             else:
                 ring = None
-            nb = max(20, a.steps // 20)
-            timed_solves(plb, states, ring, kind, 10, torch.cuda.synchronize)
+            nb = max(50, a.steps // 10)
+            plb = settle(make_batched, states, ring, kind, 50, torch.cuda.synchronize)
             plb.kernel_ms()
             elb = timed_solves(plb, states, ring, kind, nb, torch.cuda.synchronize)
             rb, fb, _ = plb.kernel_ms()

@@ -19,6 +19,7 @@ BN_MEM_HOST, BN_MEM_DEVICE = 0, 1
 (BN_BUF_STATES, BN_BUF_WEIGHTS, BN_BUF_COSTS, BN_BUF_CONTROLS, BN_BUF_USTAR, BN_BUF_XSTAR,
  BN_BUF_MEAN, BN_BUF_MAP, BN_BUF_GOAL) = range(9)
 BN_FLAG_STORE_CONTROLS, BN_FLAG_SHARED_MAP, BN_FLAG_NO_LDS_WINDOW, BN_FLAG_PROFILE, BN_FLAG_PRIVATE_STREAM = 1, 2, 4, 8, 16
+BN_FLAG_NO_PIPELINE = 32
 ABI_VERSION = 1
 
 
@@ -48,6 +49,7 @@ SYMBOLS = {
     "bn_mppi_solve": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, _FP, _FP]),
     "bn_mppi_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_sync": (C.c_int, [_H]),
+    "bn_mppi_flush": (C.c_int, [_H]),
     "bn_mppi_get_weights": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_get_costs": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_get_states": (C.c_int, [_H, C.c_int32, _FP]),

@@ -115,15 +115,14 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, fl
 
 // The library's own noise stream (BN_NOISE_PHILOX): one Philox block per (instance b, rollout k,
 // step pair p) of solve number `solve`, key = seed.  Pair p holds the (v, omega) noise of steps
-// 2p-1 and 2p (step 0 is the second half of pair 0), so the rollout loop, which peels step 0,
-// consumes whole pairs per chunk.
+// 2p and 2p+1.
 __device__ __forceinline__ void philox_eps_pair(uint64_t seed, uint64_t solve, uint32_t b, uint32_t k,
                                                 uint32_t pair, float e[4])
 {
     const u32x4 r = philox4x32_10(u32x4{k, pair, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
-    box_muller(r.x, r.y, e[0], e[1]);   // step 2*pair-1: (v, omega) noise
-    box_muller(r.z, r.w, e[2], e[3]);   // step 2*pair
+    box_muller(r.x, r.y, e[0], e[1]);   // step 2*pair: (v, omega) noise
+    box_muller(r.z, r.w, e[2], e[3]);   // step 2*pair+1
 }
 
 }  // namespace bn

@@ -54,12 +54,18 @@ struct bn_mppi {
     int n_maps = 1;
     uint64_t solves = 0;
     bool map_set = false, goal_set = false;
+    // Pipelined mode (K <= 2048): one launch per solve.  The launch of solve i merges solve i-1's
+    // per-block statistics in every rollout workgroup (warm start) and carries an aux workgroup that
+    // writes solve i-1's tail (U*, X*, weights).  `tail_pending` = the latest solve's tail has not been
+    // written yet; flush() launches the finish kernel for it.
+    bool pipelined = false;
+    bool tail_pending = false;
     // device buffers
     float *d_map = nullptr, *d_state = nullptr, *d_goal = nullptr, *d_mean = nullptr, *d_eps = nullptr;
-    float *d_X = nullptr, *d_U = nullptr, *d_cost = nullptr, *d_part = nullptr, *d_w = nullptr;
+    float *d_X = nullptr, *d_U = nullptr, *d_w = nullptr, *d_cost_out = nullptr;
+    float *d_cost[2] = {nullptr, nullptr}, *d_part[2] = {nullptr, nullptr}, *d_state_copy[2] = {nullptr, nullptr};
     float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
     int *d_idx = nullptr;
-    unsigned long long *d_counter = nullptr;
     size_t scratch_bytes = 0, eps_bytes = 0, idx_count = 0;
     float *h_pinned = nullptr;   // pinned staging for (B,3) states
     // profiling
@@ -96,6 +102,18 @@ int ensure_scratch(bn_mppi *h, size_t bytes)
     h->scratch_bytes = 0;
     BN_HIP(hipMalloc(&h->d_scratch, bytes));
     h->scratch_bytes = bytes;
+    return BN_OK;
+}
+
+// Write the tail (U*, next mean, X*, weights, cost copy) of the latest solve if it is still pending.
+int flush_tail(bn_mppi *h)
+{
+    if (!h->tail_pending) return BN_OK;
+    bn::SolveParams p = h->p;
+    const int cur = (int)((h->solves - 1) & 1);
+    p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
+    BN_HIP(bn::launch_finish(p, h->stream));
+    h->tail_pending = false;
     return BN_OK;
 }
 
@@ -218,13 +236,16 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     alloc(&h->d_mean, B * T * 2 * 4);
     alloc(&h->d_X, B * (T + 1) * 3 * (size_t)p.Kp * 4);
     if (p.store_u) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
-    alloc(&h->d_cost, B * K * 4);
-    alloc(&h->d_part, B * (size_t)p.nblk * (2 + 2 * T) * 4);
+    for (int q = 0; q < 2; ++q) {
+        alloc(&h->d_cost[q], B * K * 4);
+        alloc(&h->d_part[q], B * (size_t)p.nblk * (2 + 2 * T) * 4);
+        alloc(&h->d_state_copy[q], B * 3 * 4);
+    }
+    alloc(&h->d_cost_out, B * K * 4);
     alloc(&h->d_w, B * K * 4);
     alloc(&h->d_ustar, B * T * 2 * 4);
     alloc(&h->d_xstar, B * (T + 1) * 3 * 4);
     alloc(&h->d_stats, B * 2 * 4);
-    alloc(&h->d_counter, sizeof(unsigned long long));
     if (rc == BN_OK && hipHostMalloc((void **)&h->h_pinned, B * 3 * 4, hipHostMallocDefault) != hipSuccess)
         rc = fail(BN_ERR_HIP, "hipHostMalloc failed");
     if (rc == BN_OK) {
@@ -241,8 +262,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         return rc;
     }
     p.map = h->d_map; p.state = h->d_state; p.goal = h->d_goal; p.mean = h->d_mean; p.eps = nullptr;
-    p.X = h->d_X; p.U = h->d_U; p.cost = h->d_cost; p.part = h->d_part; p.w = h->d_w;
-    p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats; p.counter = h->d_counter;
+    p.X = h->d_X; p.U = h->d_U; p.cost = h->d_cost[0]; p.part = h->d_part[0]; p.w = h->d_w;
+    p.state_copy = h->d_state_copy[0]; p.cost_out = h->d_cost_out;
+    p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats;
+    // every rollout workgroup re-merges the previous solve's nblk partials: only worth it while they are few
+    h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 32;
     BN_HIP(hipDeviceSynchronize());
     *out = h;
     return BN_OK;
@@ -254,8 +278,9 @@ void bn_mppi_destroy(bn_mppi_t *h)
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost, h->d_part,
-                    h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_counter};
+    void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1],
+                    h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
+                    h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -272,6 +297,7 @@ int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_ki
     const hipMemcpyKind kind = where == BN_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const int lo = instance < 0 ? 0 : std::min(instance, h->n_maps - 1);
     const int hi = instance < 0 ? h->n_maps : lo + 1;
+    if (int rc = flush_tail(h)) return rc;           // the pending tail rolls X* out on the current map
     BN_HIP(hipStreamSynchronize(h->stream));
     for (int m = lo; m < hi; ++m) BN_HIP(hipMemcpy(h->d_map + (size_t)m * h->p.G * h->p.G, risk, bytes, kind));
     h->map_set = true;
@@ -283,6 +309,7 @@ int bn_mppi_set_goal(bn_mppi_t *h, int32_t instance, const float goal_host[2])
     if (int rc = check_instance(h, instance, true)) return rc;
     if (!goal_host) return fail(BN_ERR_INVALID, "goal is null");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const int lo = instance < 0 ? 0 : instance, hi = instance < 0 ? h->p.B : instance + 1;
     for (int b = lo; b < hi; ++b) BN_HIP(hipMemcpy(h->d_goal + b * 2, goal_host, 8, hipMemcpyHostToDevice));
@@ -294,6 +321,7 @@ int bn_mppi_set_mean(bn_mppi_t *h, int32_t instance, const float *mean_host)
 {
     if (int rc = check_instance(h, instance, true)) return rc;
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;           // afterwards the mean buffer is authoritative again
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->p.T * 2;
     const int lo = instance < 0 ? 0 : instance, hi = instance < 0 ? h->p.B : instance + 1;
@@ -309,6 +337,7 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!mean_host) return fail(BN_ERR_INVALID, "null output");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->p.T * 2;
     BN_HIP(hipMemcpy(mean_host, h->d_mean + instance * n, n * 4, hipMemcpyDeviceToHost));
@@ -371,11 +400,29 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
         h->ev_used += 3;
         BN_HIP(hipEventRecord(ev[0], h->stream));
     }
+    const int cur = (int)(h->solves & 1), prev = cur ^ 1;
+    p.solve = h->solves;
+    p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state_copy = h->d_state_copy[cur];
+    p.part_prev = h->d_part[prev]; p.cost_prev = h->d_cost[prev]; p.state_prev = h->d_state_copy[prev];
+    if (h->pipelined) {
+        // one launch: merge + tail of the previous solve ride along with this solve's rollouts
+        p.have_prev = h->tail_pending ? 1 : 0;
+        p.mean_from_part = h->tail_pending ? 1 : 0;
+        BN_HIP(bn::launch_rollout(p, mode, h->stream));
+        if (prof) { BN_HIP(hipEventRecord(ev[1], h->stream)); BN_HIP(hipEventRecord(ev[2], h->stream)); }
+        h->solves += 1;
+        h->tail_pending = true;
+        return BN_OK;
+    }
+    p.have_prev = 0;
+    p.mean_from_part = 0;
     BN_HIP(bn::launch_rollout(p, mode, h->stream));
     if (prof) BN_HIP(hipEventRecord(ev[1], h->stream));
+    p.state = p.state_copy;
     BN_HIP(bn::launch_finish(p, h->stream));
     if (prof) BN_HIP(hipEventRecord(ev[2], h->stream));
     h->solves += 1;
+    h->tail_pending = false;
     return BN_OK;
 }
 
@@ -383,14 +430,23 @@ int bn_mppi_sync(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     return BN_OK;
+}
+
+int bn_mppi_flush(bn_mppi_t *h)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    return flush_tail(h);
 }
 
 int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
                   bn_noise_kind noise, float *ustar_host, float *xstar_host)
 {
     if (int rc = bn_mppi_solve_async(h, states, states_where, eps, noise)) return rc;
+    if (int rc = flush_tail(h)) return rc;
     const size_t B = h->p.B, T = h->p.T;
     if (ustar_host) BN_HIP(hipMemcpyAsync(ustar_host, h->d_ustar, B * T * 2 * 4, hipMemcpyDeviceToHost, h->stream));
     if (xstar_host)
@@ -404,6 +460,7 @@ static int copy_out(bn_mppi_t *h, int32_t instance, const float *dev, size_t per
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     BN_HIP(hipMemcpy(out_host, dev + (size_t)instance * per_instance, per_instance * 4, hipMemcpyDeviceToHost));
     return BN_OK;
@@ -416,7 +473,7 @@ int bn_mppi_get_weights(bn_mppi_t *h, int32_t instance, float *out_host)
 
 int bn_mppi_get_costs(bn_mppi_t *h, int32_t instance, float *out_host)
 {
-    return h ? copy_out(h, instance, h->d_cost, h->p.K, out_host) : fail(BN_ERR_INVALID, "null handle");
+    return h ? copy_out(h, instance, h->d_cost_out, h->p.K, out_host) : fail(BN_ERR_INVALID, "null handle");
 }
 
 int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host)
@@ -470,6 +527,7 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
     const size_t K = h->p.K, T1 = h->p.T + 1;
     std::vector<float> w(K);
+    if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     BN_HIP(hipMemcpy(w.data(), h->d_w + (size_t)instance * K, K * 4, hipMemcpyDeviceToHost));
     std::vector<int> idx(K);
@@ -496,7 +554,7 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
 int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size_t *bytes)
 {
     if (!h || !device_ptr) return fail(BN_ERR_INVALID, "null argument");
-    void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal};
+    void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost_out, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal};
     if ((int)id < 0 || id >= BN_BUF_COUNT_) return fail(BN_ERR_INVALID, "unknown buffer id %d", (int)id);
     *device_ptr = ptrs[id];
     if (bytes) *bytes = buffer_bytes(h, id);
@@ -513,6 +571,7 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!(h->cfg.flags & BN_FLAG_PROFILE)) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_PROFILE");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     double r = 0.0, f = 0.0;
     const size_t n = h->ev_used / 3;

@@ -6,7 +6,8 @@
 
 namespace bn {
 
-constexpr int kRolloutsPerBlock = 64;   // one wavefront = 64 rollouts, lane = rollout
+constexpr int kRolloutsPerBlock = 64;   // lane = rollout; 64 rollouts per workgroup
+constexpr int kRolloutThreads = 256;    // 4 wavefronts per workgroup, specialised by role (chain / producers / consumer)
 constexpr int kUPad = 65;               // LDS row pitch of the control tile (bank-conflict-free both ways)
 constexpr int kFinishThreads = 256;
 
@@ -29,6 +30,9 @@ struct SolveParams {
     float sigma0, sigma1, iv0, iv1;
     float umin0, umax0, umin1, umax1;
     uint64_t seed;
+    uint64_t solve;      // index of this solve in the handle's life = Philox stream position
+    int mean_from_part;  // rollout blocks merge part_prev themselves instead of reading `mean`
+    int have_prev;       // the launch carries an aux workgroup per instance: tail of the previous solve
     const float *map;    // (n_maps, G, G)
     const float *state;  // (B, 3)
     const float *goal;   // (B, 2)
@@ -36,13 +40,15 @@ struct SolveParams {
     const float *eps;    // per EpsMode, or nullptr
     float *X;            // (B, T+1, 3, Kp)
     float *U;            // (B, T, 2, Kp) or nullptr
-    float *cost;         // (B, K)
-    float *part;         // (B, nblk, 2 + 2T): block max, block sum, block weighted control sums
+    float *cost;         // (B, K)      this solve's per-rollout costs (double-buffered by solve parity)
+    float *part;         // (B, nblk, 2 + 2T): block max, block sum, block weighted control sums (double-buffered)
+    float *state_copy;   // (B, 3)      the state this solve started from, kept for its tail
+    const float *cost_prev, *part_prev, *state_prev;   // the previous solve's buffers (pipelined mode)
+    float *cost_out;     // (B, K)      stable copy of the latest finished solve's costs (BN_BUF_COSTS)
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)
     float *stats;        // (B, 2): max z, sum exp
-    unsigned long long *counter;  // solves completed (Philox stream position), device resident
     unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0
 };
 

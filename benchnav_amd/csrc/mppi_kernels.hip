@@ -167,199 +167,9 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// Noise of steps t0 .. t0+TU-1 (t0 odd: step 0 is peeled) for rollout kk of instance b.
-template <int EPS>
-__device__ __forceinline__ void load_eps_chunk(const SolveParams &p, const float *__restrict__ eps, int b, int kk,
-                                               int t0, uint64_t solve, float (&e)[TU][2])
-{
-    if (EPS == kEpsPhilox) {
-#pragma unroll
-        for (int i = 0; i < TU / 2; ++i) {
-            float z[4];
-            philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)kk, (uint32_t)((t0 + 1) / 2 + i), z);
-            e[2 * i][0] = z[0]; e[2 * i][1] = z[1];
-            e[2 * i + 1][0] = z[2]; e[2 * i + 1][1] = z[3];
-        }
-    } else if (EPS == kEpsKT2) {
-#pragma unroll
-        for (int i = 0; i < TU; ++i) {
-            const int t = min(t0 + i, p.T - 1);
-            const float2 v = *reinterpret_cast<const float2 *>(eps + (((size_t)b * p.K + kk) * p.T + t) * 2);
-            e[i][0] = v.x; e[i][1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TU; ++i) {
-            const int t = min(t0 + i, p.T - 1);
-            const float *row = eps + ((size_t)b * p.T + t) * 2 * p.K;
-            e[i][0] = row[kk];
-            e[i][1] = row[p.K + kk];
-        }
-    }
-}
-
-template <int EPS>
-__device__ __forceinline__ void load_eps_step0(const SolveParams &p, const float *__restrict__ eps, int b, int kk,
-                                               uint64_t solve, float (&e)[2])
-{
-    if (EPS == kEpsPhilox) {
-        float z[4];
-        philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)kk, 0u, z);
-        e[0] = z[2]; e[1] = z[3];
-    } else if (EPS == kEpsKT2) {
-        const float2 v = *reinterpret_cast<const float2 *>(eps + ((size_t)b * p.K + kk) * p.T * 2);
-        e[0] = v.x; e[1] = v.y;
-    } else {
-        const float *row = eps + (size_t)b * p.T * 2 * p.K;
-        e[0] = row[kk];
-        e[1] = row[p.K + kk];
-    }
-}
-
 // ------------------------------------------------------------------------------
-// Rollout + cost kernel.  grid = (ceil(K/64), B), block = 64 (one wavefront).
-// LDS: [ window WN*WN | mean 2T | mean*inv_var 2T | control tile 2T x 65 | e 64 ]
-// ------------------------------------------------------------------------------
-template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
-__global__ __launch_bounds__(kRolloutsPerBlock) void rollout_kernel(const SolveParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int T = p.T, K = p.K;
-    float *win = smem;
-    float *ml = win + (LDSWIN ? p.WN * p.WN : 0);
-    float *mv = ml + 2 * T;
-    float *Ul = mv + 2 * T;
-    float *el = Ul + 2 * T * kUPad;
-
-    const int lane = threadIdx.x;
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * kRolloutsPerBlock + lane;
-    const bool active = k < K;
-    const int kk = active ? k : K - 1;
-
-    const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
-    const float *__restrict__ eps = p.eps;
-    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
-    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
-    const uint64_t solve = (EPS == kEpsPhilox) ? (uint64_t)*p.counter : 0;
-    BN_STAMP(0);
-
-    float e0[2];
-    float ecur[TU][2], enext[TU][2];
-    load_eps_step0<EPS>(p, eps, b, kk, solve, e0);
-    load_eps_chunk<EPS>(p, eps, b, kk, 1, solve, ecur);
-
-    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
-    if (LDSWIN) {
-        w = window_origin<GEO>(p, sx, sy);
-        stage_window(win, map, w, p.WN, p.G, lane, kRolloutsPerBlock);
-    }
-    for (int j = lane; j < 2 * T; j += kRolloutsPerBlock) {
-        const float m = p.mean[(size_t)b * 2 * T + j];
-        ml[j] = m;
-        mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);      // mean[t] @ inv_cov (diagonal), mppi.py:179-180
-    }
-    __syncthreads();
-    BN_STAMP(1);
-
-    Chain c;
-    c.x = sx; c.y = sy; c.th = sth;                   // mppi.py:160
-    sincos_spec(c.th, c.sn, c.cs);
-    c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
-    double Sd = 0.0, Ad = 0.0;                        // fp64 accumulation of the fp32 terms (Arithmetic spec)
-    float Sf = 0.0f, Af = 0.0f;                       // (ablation builds only)
-    // Rows of X and U are pitched to Kp = 64 * nblk floats, so every lane stores unconditionally
-    // (lanes past K write into the pad) and the step body stays one basic block.
-    const size_t Kp = (size_t)p.Kp;
-    float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
-    float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
-
-    // One time step for this lane's rollout: sample the control, advance the chain, emit slot t,
-    // accumulate the control cost and the stage cost of the aliased slot.
-#define BN_STEP(FIRST, t, eps0, eps1)                                                                          \
-    do {                                                                                                       \
-        const float m0 = ml[2 * (t)], m1 = ml[2 * (t) + 1];                                                    \
-        const float u0 = clampf(m0 + p.sigma0 * (eps0), p.umin0, p.umax0);   /* mppi.py:152-157 */             \
-        const float u1 = clampf(m1 + p.sigma1 * (eps1), p.umin1, p.umax1);                                     \
-        float xn, yn, tn;                                                                                      \
-        chain_step<GEO, LDSWIN, FIRST>(p, win, map, w, c, u0, u1, xn, yn, tn);                                 \
-        if (!(BN_ABLATE & 8)) {                                                                                \
-        Ul[(2 * (t)) * kUPad + lane] = u0;                                                                     \
-        Ul[(2 * (t) + 1) * kUPad + lane] = u1;                                                                 \
-        }                                                                                                      \
-        if (!(BN_ABLATE & 4)) {                                                                                \
-        float *Xt = Xb + (size_t)(3 * (t)) * Kp;         /* slot t keeps the un-clamped state (aliasing) */     \
-        Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                              \
-        } else { BN_KEEP(xn); BN_KEEP(yn); BN_KEEP(tn); }                                                      \
-        if (STORE_U) { float *Ut = Ub + (size_t)(2 * (t)) * Kp; Ut[0] = u0; Ut[Kp] = u1; }                     \
-        if (!(BN_ABLATE & 8)) {                                                                                \
-        const float a = mv[2 * (t)] * u0 + mv[2 * (t) + 1] * u1;            /* mppi.py:178-182 */             \
-        if (BN_ABLATE & 2) Af += p.lambda_ * a; else                                                           \
-        Ad += (double)(p.lambda_ * a);                                                                         \
-        }                                                                                                      \
-        /* the cell of the un-clamped slot equals the cell of the clamped state (index clamp,               */ \
-        /* grid_map.py:209), so c.trav serves stage cost t and transit t+1                                  */ \
-        if (!(BN_ABLATE & 1)) {                                                                                \
-        const float dx = xn - gx, dy = yn - gy;                                                                \
-        const float sc = sqrtf(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f);   /* objectives.py:47-53 */ \
-        if (BN_ABLATE & 2) Sf += sc; else                                                                      \
-        Sd += (double)sc;                                                                                      \
-        }                                                                                                      \
-    } while (0)
-
-    BN_STEP(true, 0, e0[0], e0[1]);
-    BN_STAMP(2);
-    int t0 = 1;
-    for (; t0 + TU <= T; t0 += TU) {
-        load_eps_chunk<EPS>(p, eps, b, kk, t0 + TU, solve, enext);      // indices clamp at T-1: always in bounds
-#pragma unroll
-        for (int i = 0; i < TU; ++i) BN_STEP(false, t0 + i, ecur[i][0], ecur[i][1]);
-#pragma unroll
-        for (int i = 0; i < TU; ++i) { ecur[i][0] = enext[i][0]; ecur[i][1] = enext[i][1]; }
-    }
-#pragma unroll
-    for (int i = 0; i < TU - 1; ++i)
-        if (t0 + i < T) BN_STEP(false, t0 + i, ecur[i][0], ecur[i][1]);
-#undef BN_STEP
-    BN_STAMP(3);
-
-    {                                                  // slot T: clamped / wrapped state
-        float *Xt = Xb + (size_t)(3 * T) * Kp;
-        Xt[0] = c.x; Xt[Kp] = c.y; Xt[2 * Kp] = c.th;
-    }
-    const float dxT = c.x - gx, dyT = c.y - gy;
-    const float term = sqrtf(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);     // mppi.py:184
-#if BN_ABLATE
-    const float cost = (((float)Sd + Sf) + term) + ((float)Ad + Af);
-#else
-    const float cost = ((float)Sd + term) + (float)Ad;                                         // mppi.py:186-190
-#endif
-    if (active) p.cost[(size_t)b * K + k] = cost;
-
-    // block-local softmin statistics   mppi.py:193-199
-    const float z = active ? (-cost) / p.lambda_ : -INFINITY;
-    const float zmax = wave_max(z);
-    const float e = active ? expf(z - zmax) : 0.0f;
-    const float esum = wave_sum(e);
-    el[lane] = e;
-    __syncthreads();
-    BN_STAMP(4);
-    float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
-    for (int j = lane; j < 2 * T; j += kRolloutsPerBlock) {
-        const float *col = Ul + j * kUPad;
-        float acc = 0.0f;
-#pragma unroll 16
-        for (int q = 0; q < kRolloutsPerBlock; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
-        part[2 + j] = acc;
-    }
-    if (lane == 0) { part[0] = zmax; part[1] = esum; }
-    BN_STAMP(5);
-}
-
-// ------------------------------------------------------------------------------
-// Finish kernel.  grid = B, block = 256.  Merges the per-block statistics,
-// writes U* (and the next mean), the normalised weights, and rolls out X*.
-// LDS: [ window | ustar 2T | scale nblk | red 256 ]
+// Softmin merge and the tail of a solve (shared by the finish kernel, the aux block of the
+// pipelined rollout kernel, and the rollout blocks' own prologue merge).
 // ------------------------------------------------------------------------------
 __device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool is_max)
 {
@@ -372,10 +182,72 @@ __device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool
     return r;
 }
 
-template <int GEO, bool LDSWIN>
-__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParams p)
+// Merge the nblk per-block statistics (max z, sum e, sum e*u) of one instance into
+//   U*[j] = sum_k w_k u_k[j]      mppi.py:193-199
+// written to us[0..2T) (LDS).  Deterministic: every caller (256 threads) gets bit-identical values,
+// which is what lets each rollout block of the next solve recompute the warm-start mean on its own.
+// LDS scratch: sc[nblk], red[4].  Returns (max z, sum exp) for the weights.
+constexpr int kMergePrefetch = 16;
+__device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
+                                               float *red, int tid, float &m_out, float &S_out)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int PS = 2 + 2 * T;
+    const int lane = tid & 63;
+    float m, S;
+    if (nblk <= 64) {
+        // Few blocks (K <= 4096): every wave reduces the nblk (max, sum) pairs itself with shuffles --
+        // same inputs, same operations, so all waves (and all workgroups) hold identical m, S and
+        // scales -- and all loads are issued before the first use: one memory round trip, one barrier.
+        const int j = tid < 2 * T ? tid : 0;
+        float v[kMergePrefetch];
+#pragma unroll
+        for (int i = 0; i < kMergePrefetch; ++i) v[i] = part[(size_t)min(i, nblk - 1) * PS + 2 + j];
+        const bool has = lane < nblk;
+        const float mi = has ? part[(size_t)lane * PS] : -INFINITY;
+        const float si = has ? part[(size_t)lane * PS + 1] : 0.0f;
+        m = wave_max(mi);
+        const float f = has ? expf(mi - m) : 0.0f;       // scale of block `lane`; 0 past nblk
+        S = wave_sum(si * f);
+        for (int jj = tid; jj < 2 * T; jj += kFinishThreads) {
+            float acc = 0.0f;
+            if (jj == j) {
+#pragma unroll
+                for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(v[i], __shfl(f, i), acc);   // f == 0 past nblk
+                for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], __shfl(f, i), acc);
+            } else {
+                for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], __shfl(f, i), acc);
+            }
+            us[jj] = acc / S;
+        }
+    } else {
+        float mm = -INFINITY;
+        for (int i = tid; i < nblk; i += kFinishThreads) mm = fmaxf(mm, part[(size_t)i * PS]);
+        m = block_reduce(mm, red, tid, true);
+        float s = 0.0f;
+        for (int i = tid; i < nblk; i += kFinishThreads) {
+            const float f = expf(part[(size_t)i * PS] - m);
+            sc[i] = f;
+            s += part[(size_t)i * PS + 1] * f;
+        }
+        S = block_reduce(s, red, tid, false);            // the barrier inside also publishes sc[]
+        for (int jj = tid; jj < 2 * T; jj += kFinishThreads) {
+            float acc = 0.0f;
+            for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], sc[i], acc);
+            us[jj] = acc / S;
+        }
+    }
+    __syncthreads();
+    m_out = m;
+    S_out = S;
+}
+
+// The tail of one solve of instance b: U* (and the next mean), softmin statistics, normalised weights,
+// a stable copy of the costs, and the batch-1 rollout X* of U*.  256 threads.
+// LDS: [ window | ustar 2T | scale nblk | red 4 ]
+template <int GEO, bool LDSWIN>
+__device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
+                                            const float *state_all, float *smem)
+{
     const int T = p.T, K = p.K, nblk = p.nblk, PS = 2 + 2 * p.T;
     float *win = smem;
     float *us = win + (LDSWIN ? p.WN * p.WN : 0);
@@ -383,10 +255,9 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParam
     float *red = sc + nblk;
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
     const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
-    const float *part = p.part + (size_t)b * nblk * PS;
-    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    const float *part = part_all + (size_t)b * nblk * PS;
+    const float sx = state_all[b * 3 + 0], sy = state_all[b * 3 + 1], sth = state_all[b * 3 + 2];
     BN_STAMP(8);
 
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
@@ -396,31 +267,16 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParam
     }
     BN_STAMP(9);
 
-    float m = -INFINITY;
-    for (int i = tid; i < nblk; i += kFinishThreads) m = fmaxf(m, part[(size_t)i * PS]);
-    m = block_reduce(m, red, tid, true);
-    float s = 0.0f;
-    for (int i = tid; i < nblk; i += kFinishThreads) {
-        const float f = expf(part[(size_t)i * PS] - m);
-        sc[i] = f;
-        s += part[(size_t)i * PS + 1] * f;
-    }
-    const float S = block_reduce(s, red, tid, false);   // also publishes sc[] (barrier inside)
-
+    float m, S;
+    merge_partials(part, nblk, T, us, sc, red, tid, m, S);
     for (int j = tid; j < 2 * T; j += kFinishThreads) {
-        float acc = 0.0f;
-        for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + j], sc[i], acc);
-        const float u = acc / S;                         // sum_k w_k u_k, mppi.py:196-199
-        us[j] = u;
-        p.ustar[(size_t)b * 2 * T + j] = u;
-        p.mean[(size_t)b * 2 * T + j] = u;               // _previous_action_seq = U*, no shift (mppi.py:217)
+        p.ustar[(size_t)b * 2 * T + j] = us[j];
+        p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
     }
     if (tid == 0) {
         p.stats[b * 2 + 0] = m;
         p.stats[b * 2 + 1] = S;
-        if (b == 0) *p.counter += 1ull;
     }
-    __syncthreads();
     BN_STAMP(10);
 
     if (tid == 0) {
@@ -441,11 +297,265 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParam
         BN_STAMP(11);
     } else if (tid >= 64) {
         // _weights = softmax(-costs / lambda)   mppi.py:193
-        const float *cost = p.cost + (size_t)b * K;
+        const float *cost = cost_all + (size_t)b * K;
         float *wout = p.w + (size_t)b * K;
-        for (int k = tid - 64; k < K; k += kFinishThreads - 64)
-            wout[k] = expf((-cost[k]) / p.lambda_ - m) / S;
+        float *cout = p.cost_out + (size_t)b * K;
+        for (int k = tid - 64; k < K; k += kFinishThreads - 64) {
+            const float ck = cost[k];
+            cout[k] = ck;
+            wout[k] = expf((-ck) / p.lambda_ - m) / S;
+        }
     }
+}
+
+// Workgroup barrier that only drains LDS traffic: global stores of the consumer wave stay in flight.
+#define BN_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Producer: the clamped perturbed controls of steps t and t+1 (t even) of this lane's rollout,
+//   u = clamp(mean + sigma * eps, u_min, u_max)          mppi.py:152-157
+// written to the LDS control tile (and to HBM when _perturbed_action_seqs is materialised).
+template <int EPS, bool STORE_U>
+__device__ __forceinline__ void produce_pair(const SolveParams &p, const float *__restrict__ eps, int b, int kk, int t,
+                                             uint64_t solve, const float *ml, float *Ul, float *Ub, size_t Kp, int lane)
+{
+    float e[4];
+    const int t1 = min(t + 1, p.T - 1);
+    if (EPS == kEpsPhilox) {
+        philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(t >> 1), e);
+    } else if (EPS == kEpsKT2) {
+        const float *row = eps + ((size_t)b * p.K + kk) * p.T * 2;
+        const float2 v0 = *reinterpret_cast<const float2 *>(row + 2 * t);
+        const float2 v1 = *reinterpret_cast<const float2 *>(row + 2 * t1);
+        e[0] = v0.x; e[1] = v0.y; e[2] = v1.x; e[3] = v1.y;
+    } else {
+        const float *r0 = eps + ((size_t)b * p.T + t) * 2 * p.K;
+        const float *r1 = eps + ((size_t)b * p.T + t1) * 2 * p.K;
+        e[0] = r0[kk]; e[1] = r0[p.K + kk]; e[2] = r1[kk]; e[3] = r1[p.K + kk];
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int tt = t + s;
+        if (tt < p.T) {
+            const float u0 = clampf(ml[2 * tt] + p.sigma0 * e[2 * s], p.umin0, p.umax0);
+            const float u1 = clampf(ml[2 * tt + 1] + p.sigma1 * e[2 * s + 1], p.umin1, p.umax1);
+            Ul[(2 * tt) * kUPad + lane] = u0;
+            Ul[(2 * tt + 1) * kUPad + lane] = u1;
+            if (STORE_U) { float *Ut = Ub + (size_t)(2 * tt) * Kp; Ut[0] = u0; Ut[Kp] = u1; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Rollout + cost kernel.  grid = (ceil(K/64), B), block = 256 = 4 wavefronts that all map
+// lane -> rollout k = 64*blockIdx.x + lane and split the work of those 64 rollouts by ROLE,
+// because one wavefront issues at most one instruction every ~4.5-6.5 cycles (measured,
+// tools/ubench.hip) and the T-step recurrence is a serial instruction chain:
+//   wave 0  chain     the recurrence only: transit + gather (chain_step), ~60 instructions/step
+//   wave 1  producer  noise -> clamped controls for the first half of chunk c+2
+//   wave 3  producer  ... second half of chunk c+2
+//   wave 2  consumer  chunk c-1: trajectory stores, control cost, stage cost, fp64 accumulation
+// Chunks are TU = 4 steps; one LDS-only barrier per chunk hands the control tile forward and the
+// chain's outputs (ring of 2 chunks) backward.  The per-rollout sums are accumulated by one wave in
+// step order, so the arithmetic is identical to a single sequential loop (Arithmetic spec).
+// LDS: [ window WN*WN | mean 2T | mean*inv_var 2T | control tile 2T x 65 | ring 2 x TU x 4 x 64 |
+//        final state 4 x 64 | e 64 ]
+// ------------------------------------------------------------------------------
+template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
+__global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolveParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.x == p.nblk) {
+        // pipelined mode: the extra workgroup computes the tail of the PREVIOUS solve (U*, X*, weights)
+        // while the other workgroups roll out this one
+        finish_body<GEO, LDSWIN>(p, blockIdx.y, p.part_prev, p.cost_prev, p.state_prev, smem);
+        return;
+    }
+    const int T = p.T, K = p.K;
+    float *win = smem;
+    float *ml = win + (LDSWIN ? p.WN * p.WN : 0);
+    float *mv = ml + 2 * T;
+    float *Ul = mv + 2 * T;
+    float *ring = Ul + 2 * T * kUPad;
+    float *fin = ring + 2 * TU * 4 * 64;
+    float *el = fin + 4 * 64;
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * kRolloutsPerBlock + lane;
+    const bool active = k < K;
+    const int kk = active ? k : K - 1;
+
+    const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
+    const float *__restrict__ eps = p.eps;
+    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
+    const uint64_t solve = p.solve;
+    BN_STAMP(0);
+
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (LDSWIN) {
+        w = window_origin<GEO>(p, sx, sy);
+        stage_window(win, map, w, p.WN, p.G, tid, kRolloutThreads);
+    }
+    if (p.mean_from_part) {
+        // warm start straight from the previous solve's per-block statistics (bit-identical to the U*
+        // the aux block publishes): no kernel boundary between consecutive solves of one instance
+        float m_unused, S_unused;
+        merge_partials(p.part_prev + (size_t)b * p.nblk * (2 + 2 * T), p.nblk, T, ml, ring, ring + p.nblk, tid,
+                       m_unused, S_unused);
+        for (int j = tid; j < 2 * T; j += kRolloutThreads) mv[j] = ml[j] * ((j & 1) ? p.iv1 : p.iv0);
+    } else {
+        for (int j = tid; j < 2 * T; j += kRolloutThreads) {
+            const float m = p.mean[(size_t)b * 2 * T + j];
+            ml[j] = m;
+            mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);      // mean[t] @ inv_cov (diagonal), mppi.py:179-180
+        }
+    }
+    if (blockIdx.x == 0 && tid < 3) p.state_copy[b * 3 + tid] = p.state[b * 3 + tid];   // for this solve's tail
+    BN_BAR();
+
+    // Rows of X and U are pitched to Kp = 64 * nblk floats, so every lane stores unconditionally
+    // (lanes past K write into the pad).
+    const size_t Kp = (size_t)p.Kp;
+    float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
+    float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
+
+    // controls of chunks 0 and 1 (steps 0..7): two steps per wave
+    if (2 * wv < T) produce_pair<EPS, STORE_U>(p, eps, b, kk, 2 * wv, solve, ml, Ul, Ub, Kp, lane);
+    BN_BAR();
+    BN_STAMP(1);
+
+    Chain c;                                          // wave 0
+    double Sd = 0.0, Ad = 0.0;                        // wave 2: fp64 accumulation of the fp32 terms (Arithmetic spec)
+    if (wv == 0) {
+        c.x = sx; c.y = sy; c.th = sth;               // mppi.py:160
+        sincos_spec(c.th, c.sn, c.cs);
+        c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
+    }
+
+    // wave 0: one chain step; emits what the reference leaves in slot t plus the traversability of state t+1
+#define BN_CHAIN(FIRST, t, slot)                                                                               \
+    do {                                                                                                       \
+        const float u0 = Ul[(2 * (t)) * kUPad + lane], u1 = Ul[(2 * (t) + 1) * kUPad + lane];                  \
+        float xn, yn, tn;                                                                                      \
+        chain_step<GEO, LDSWIN, FIRST>(p, win, map, w, c, u0, u1, xn, yn, tn);                                 \
+        float *o = (slot) + lane;                                                                              \
+        o[0] = xn; o[64] = yn; o[128] = tn; o[192] = c.trav;                                                   \
+    } while (0)
+
+    // wave 2: everything per step that is not on the recurrence
+#define BN_CONSUME(t, slot)                                                                                    \
+    do {                                                                                                       \
+        const float *o = (slot) + lane;                                                                        \
+        const float xn = o[0], yn = o[64], tn = o[128], trn = o[192];                                          \
+        float *Xt = Xb + (size_t)(3 * (t)) * Kp;         /* slot t keeps the un-clamped state (aliasing) */     \
+        Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                              \
+        const float u0 = Ul[(2 * (t)) * kUPad + lane], u1 = Ul[(2 * (t) + 1) * kUPad + lane];                  \
+        const float a = mv[2 * (t)] * u0 + mv[2 * (t) + 1] * u1;            /* mppi.py:178-182 */             \
+        Ad += (double)(p.lambda_ * a);                                                                         \
+        /* the cell of the un-clamped slot equals the cell of the clamped state (index clamp,               */ \
+        /* grid_map.py:209), so the chain's gather serves stage cost t and transit t+1                      */ \
+        const float dx = xn - gx, dy = yn - gy;                                                                \
+        const float sc = sqrtf(dx * dx + dy * dy) + (trn <= p.thr ? 1.0e4f : 0.0f);   /* objectives.py:47-53 */ \
+        Sd += (double)sc;                                                                                      \
+    } while (0)
+
+    // One phase = one chunk of TU steps for the chain, the previous chunk for the consumer, the
+    // chunk after next for the producers.  GUARD handles the ragged last chunk.
+#define BN_PHASE(cc, FIRSTCHUNK, GUARD)                                                                        \
+    do {                                                                                                       \
+        if (wv == 0) {                                                                                         \
+            if ((cc) * TU < T) {                                                                               \
+                float *slot = ring + (((cc) & 1) * TU) * 256;                                                  \
+                _Pragma("unroll") for (int i = 0; i < TU; ++i) {                                               \
+                    const int t = (cc) * TU + i;                                                               \
+                    if (!(GUARD) || t < T) {                                                                   \
+                        if ((FIRSTCHUNK) && i == 0) BN_CHAIN(true, t, slot + i * 256);                         \
+                        else BN_CHAIN(false, t, slot + i * 256);                                               \
+                    }                                                                                          \
+                }                                                                                              \
+            }                                                                                                  \
+        } else if (wv == 2) {                                                                                  \
+            if ((cc) >= 1) {                                                                                   \
+                const float *slot = ring + ((((cc) - 1) & 1) * TU) * 256;                                      \
+                _Pragma("unroll") for (int i = 0; i < TU; ++i) {                                               \
+                    const int t = ((cc) - 1) * TU + i;                                                         \
+                    if (!(GUARD) || t < T) BN_CONSUME(t, slot + i * 256);                                      \
+                }                                                                                              \
+            }                                                                                                  \
+        } else {                                                                                               \
+            const int t = ((cc) + 2) * TU + (wv == 1 ? 0 : 2);                                                 \
+            if (t < T) produce_pair<EPS, STORE_U>(p, eps, b, kk, t, solve, ml, Ul, Ub, Kp, lane);              \
+        }                                                                                                      \
+    } while (0)
+
+    const int nfull = T / TU;                         // chunks with all TU steps
+    BN_PHASE(0, true, true);
+    BN_BAR();
+    BN_STAMP(2);
+    int cc = 1;
+    for (; cc < nfull; ++cc) {                        // steady state: chunks cc (chain) and cc-1 (consumer) are full
+        BN_PHASE(cc, false, false);
+        BN_BAR();
+    }
+    for (; cc * TU < T + TU; ++cc) {                  // ragged tail and the consumer's drain
+        BN_PHASE(cc, false, true);
+        BN_BAR();
+    }
+#undef BN_PHASE
+#undef BN_CONSUME
+#undef BN_CHAIN
+    BN_STAMP(3);
+
+    if (wv == 0) {                                     // state T (clamped / wrapped) and its traversability
+        fin[lane] = c.x; fin[64 + lane] = c.y; fin[128 + lane] = c.th; fin[192 + lane] = c.trav;
+    }
+    BN_BAR();
+
+    if (wv == 2) {
+        const float xT = fin[lane], yT = fin[64 + lane], thT = fin[128 + lane], trT = fin[192 + lane];
+        float *Xt = Xb + (size_t)(3 * T) * Kp;         // slot T: clamped / wrapped state
+        Xt[0] = xT; Xt[Kp] = yT; Xt[2 * Kp] = thT;
+        const float dxT = xT - gx, dyT = yT - gy;
+        const float term = sqrtf(dxT * dxT + dyT * dyT) + (trT <= p.thr ? 1.0e4f : 0.0f);    // mppi.py:184
+        const float cost = ((float)Sd + term) + (float)Ad;                                     // mppi.py:186-190
+        if (active) p.cost[(size_t)b * K + k] = cost;
+        // block-local softmin statistics   mppi.py:193-199
+        const float z = active ? (-cost) / p.lambda_ : -INFINITY;
+        const float zmax = wave_max(z);
+        const float e = active ? expf(z - zmax) : 0.0f;
+        const float esum = wave_sum(e);
+        el[lane] = e;
+        if (lane == 0) {
+            float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+            part[0] = zmax; part[1] = esum;
+        }
+    }
+    BN_BAR();
+    BN_STAMP(4);
+    {   // weighted control sums of this block: column j of the tile, 4 waves x 64 lanes over 2T columns
+        float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+        for (int j = tid; j < 2 * T; j += kRolloutThreads) {
+            const float *col = Ul + j * kUPad;
+            float acc = 0.0f;
+#pragma unroll 16
+            for (int q = 0; q < kRolloutsPerBlock; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
+            part[2 + j] = acc;
+        }
+    }
+    BN_STAMP(5);
+}
+
+// ------------------------------------------------------------------------------
+// Finish kernel.  grid = B, block = 256: finish_body for the latest solve (also the flush of the
+// pipelined mode).
+// ------------------------------------------------------------------------------
+template <int GEO, bool LDSWIN>
+__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    finish_body<GEO, LDSWIN>(p, blockIdx.x, p.part, p.cost, p.state, smem);
 }
 
 // ---- layout helpers -----------------------------------------------------------
@@ -470,14 +580,14 @@ __global__ void gather_states_kernel(const float *__restrict__ X, const int *__r
 
 __global__ void philox_noise_kernel(float *__restrict__ eps, uint64_t seed, uint64_t solve, int b, int K, int T)
 {   // eps (K, T, 2) of one instance, exactly the stream rollout_kernel<kEpsPhilox> consumes
-    const int npair = T / 2 + 1;                    // pair p = steps (2p-1, 2p)
+    const int npair = (T + 1) / 2;                  // pair p = steps (2p, 2p+1)
     const size_t tot = (size_t)K * npair;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i / npair), pr = (int)(i - (size_t)k * npair);
         float z[4];
         philox_eps_pair(seed, solve, (uint32_t)b, (uint32_t)k, (uint32_t)pr, z);
-        const int t = 2 * pr - 1;
-        if (t >= 0) {
+        const int t = 2 * pr;
+        {
             eps[((size_t)k * T + t) * 2 + 0] = z[0];
             eps[((size_t)k * T + t) * 2 + 1] = z[1];
         }
@@ -507,7 +617,7 @@ hipError_t launch_rollout_u(const SolveParams &p, hipStream_t s)
     const size_t lds = rollout_lds_bytes(p);
     hipError_t e = ensure_lds(rollout_kernel<EPS, GEO, LDSWIN, STORE_U>, lds);
     if (e != hipSuccess) return e;
-    rollout_kernel<EPS, GEO, LDSWIN, STORE_U><<<dim3(p.nblk, p.B), dim3(kRolloutsPerBlock), lds, s>>>(p);
+    rollout_kernel<EPS, GEO, LDSWIN, STORE_U><<<dim3(p.nblk + (p.have_prev ? 1 : 0), p.B), dim3(kRolloutThreads), lds, s>>>(p);
     return hipGetLastError();
 }
 
@@ -542,7 +652,7 @@ hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
 
 size_t rollout_lds_bytes(const SolveParams &p)
 {
-    return sizeof(float) * ((size_t)p.WN * p.WN + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad + kRolloutsPerBlock);
+    return sizeof(float) * ((size_t)p.WN * p.WN + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad + 2 * 4 * 4 * 64 + 4 * 64 + 64);
 }
 
 size_t finish_lds_bytes(const SolveParams &p)
@@ -591,7 +701,7 @@ hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, 
 
 hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s)
 {
-    philox_noise_kernel<<<grid_for((size_t)K * (T / 2 + 1)), 256, 0, s>>>(eps_kt2, seed, solve, b, K, T);
+    philox_noise_kernel<<<grid_for((size_t)K * ((T + 1) / 2)), 256, 0, s>>>(eps_kt2, seed, solve, b, K, T);
     return hipGetLastError();
 }
 

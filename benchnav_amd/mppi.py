@@ -188,6 +188,7 @@ class MPPI(nn.Module):
 
     @_previous_action_seq.setter
     def _previous_action_seq(self, value: torch.Tensor) -> None:
+        _capi.check(self._lib.bn_mppi_flush(self._handle))            # the mean buffer is authoritative after a flush
         self._buf_mean.copy_(torch.as_tensor(value).to(self._device, self._dtype))
 
     @property
@@ -235,6 +236,7 @@ class MPPI(nn.Module):
         self._last_state = st                                          # keep alive until the kernels ran
         _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
                                                   eptr, kind))
+        _capi.check(self._lib.bn_mppi_flush(self._handle))            # U*, X*, weights of THIS solve, stream-ordered
         if self._copy_outputs:
             return self._buf_ustar.clone(), self._buf_xstar.clone()
         return self._buf_ustar, self._buf_xstar
@@ -250,6 +252,7 @@ class MPPI(nn.Module):
         self._last_state = st
         _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
                                                   C.c_void_p(self._eps_dev.data_ptr()), _capi.BN_NOISE_DEVICE_KT2))
+        _capi.check(self._lib.bn_mppi_flush(self._handle))
         return self._buf_ustar.clone(), self._buf_xstar.clone()
 
     def get_top_samples(self, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -31,7 +31,7 @@ class NativeMPPI:
                  sigmas=(0.5, 0.5), inv_var=None, lambda_: float = 0.5, u_min=(0.0, -1.0), u_max=(1.0, 1.0),
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
-                 profile: bool = False, stream: Optional[int] = None):
+                 profile: bool = False, stream: Optional[int] = None, pipeline: bool = True):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -56,7 +56,8 @@ class NativeMPPI:
                      | (_capi.BN_FLAG_SHARED_MAP if shared_map else 0)
                      | (0 if lds_window else _capi.BN_FLAG_NO_LDS_WINDOW)
                      | (_capi.BN_FLAG_PROFILE if profile else 0)
-                     | (_capi.BN_FLAG_PRIVATE_STREAM if stream is None else 0))
+                     | (_capi.BN_FLAG_PRIVATE_STREAM if stream is None else 0)
+                     | (0 if pipeline else _capi.BN_FLAG_NO_PIPELINE))
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
         self.store_controls = store_controls
@@ -120,7 +121,12 @@ class NativeMPPI:
                                                   C.c_void_p(eps_ptr), kind))
 
     def sync(self):
+        """Write the pending tail of the latest solve and wait for the stream."""
         _capi.check(self._lib.bn_mppi_sync(self._h))
+
+    def flush(self):
+        """Enqueue the pending tail (U*, X*, weights of the latest solve) without waiting."""
+        _capi.check(self._lib.bn_mppi_flush(self._h))
 
     # -- outputs (reference layouts) -------------------------------------------------------
     def weights(self, instance: int = 0) -> np.ndarray:

@@ -70,7 +70,8 @@ enum {
     BN_FLAG_SHARED_MAP = 1u << 1,      /* all B instances plan on map 0                      */
     BN_FLAG_NO_LDS_WINDOW = 1u << 2,   /* debug: gather the risk map from global memory      */
     BN_FLAG_PROFILE = 1u << 3,         /* record HIP events around each kernel (see bn_mppi_kernel_ms) */
-    BN_FLAG_PRIVATE_STREAM = 1u << 4   /* ignore `stream`: the library creates and owns a non-blocking stream */
+    BN_FLAG_PRIVATE_STREAM = 1u << 4,  /* ignore `stream`: the library creates and owns a non-blocking stream */
+    BN_FLAG_NO_PIPELINE = 1u << 5      /* always two launches per solve (rollout, finish); see bn_mppi_solve_async */
 };
 
 /*
@@ -139,10 +140,17 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host);
  */
 int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
                   bn_noise_kind noise, float *ustar_host, float *xstar_host);
-/* Same, enqueue only: results stay in the device buffers (bn_mppi_device_buffer). */
+/* Same, enqueue only: results stay in the device buffers (bn_mppi_device_buffer).
+ * For K <= 2048 consecutive async solves are software-pipelined: the launch of solve i also merges
+ * solve i-1's softmin statistics (its warm start) and writes solve i-1's U*, X* and weights, so a
+ * dependent chain of solves costs one launch each.  bn_mppi_sync, bn_mppi_solve and every getter
+ * first write the pending tail of the latest solve; device buffers obtained with
+ * bn_mppi_device_buffer are up to date after bn_mppi_sync (or bn_mppi_flush + stream order). */
 int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where,
                         const float *eps, bn_noise_kind noise);
 int bn_mppi_sync(bn_mppi_t *h);
+/* Enqueue the pending tail (if any) without waiting. */
+int bn_mppi_flush(bn_mppi_t *h);
 
 /* Copies of the planner state in the REFERENCE's layouts (host arrays).  All
  * synchronise the stream first.

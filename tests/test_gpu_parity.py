@@ -51,6 +51,40 @@ def test_free_running_warm_start_tracks_the_reference():
         assert pl.solve_count() == int(fx["n_solves"])
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_pipelined_async_chain_equals_synchronous_chain(B):
+    """K <= 2048: consecutive async solves are software-pipelined (one launch each: the launch of solve i
+    merges solve i-1's statistics and writes solve i-1's tail).  The results must be bit-identical to
+    the same chain run with a flush after every solve and to the two-launch (non-pipelined) path."""
+    import torch
+    from benchnav_amd import NativeMPPI, _capi
+    fx = load_case("c1_basic")
+    K, T, G = int(fx["K"]), int(fx["T"]), int(fx["G"])
+    n = 6
+    rng = np.random.default_rng(3)
+    eps = [torch.from_numpy(rng.standard_normal((B, K, T, 2)).astype(np.float32)).cuda() for _ in range(n)]
+    states = [torch.from_numpy(np.tile(fx["state_0"], (B, 1)) + 0.3 * i + 0.1 * np.arange(B)[:, None]).float().cuda()
+              for i in range(n)]
+    torch.cuda.synchronize()
+    results = {}
+    for mode in ("pipelined", "flushed", "two_launch"):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=float(fx["res"]), num_instances=B,
+                        shared_map=True, store_controls=True, pipeline=(mode != "two_launch")) as pl:
+            pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
+            for i in range(n):
+                pl.solve_async_device(states[i].data_ptr(), eps[i].data_ptr(), _capi.BN_NOISE_DEVICE_KT2)
+                if mode == "flushed":
+                    pl.sync()
+            pl.sync()
+            results[mode] = [(pl.states(b), pl.costs(b), pl.weights(b), pl.get_mean(b), pl.controls(b)) for b in range(B)]
+            assert pl.solve_count() == n
+    for mode in ("flushed", "two_launch"):
+        for b in range(B):
+            for got, ref in zip(results["pipelined"][b], results[mode][b]):
+                assert np.array_equal(got, ref), mode
+    assert not np.array_equal(results["pipelined"][0][3], np.zeros((T, 2), np.float32))
+
+
 def test_noise_layouts_and_state_memory_kinds_agree_bitwise():
     import torch
     from benchnav_amd import _capi

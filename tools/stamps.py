@@ -3,7 +3,7 @@
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "_ablate", "lib_timing.so")
+LIB = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ.get("BN_VARIANT", "timing"))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     from benchnav_amd import build as b
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -26,6 +26,13 @@ for noise in ("philox", "t2k"):
         if noise == "philox": pl.solve_async_device(st.data_ptr())
         else: pl.solve_async_device(st.data_ptr(), eps.data_ptr(), _capi.BN_NOISE_DEVICE_T2K)
         pl.sync(); acc.append(stamps.cpu().numpy().copy())
+    # pipelined steady state: back-to-back async solves, stamps of the last launch (prologue includes the merge)
+    for _ in range(30):
+        if noise == "philox": pl.solve_async_device(st.data_ptr())
+        else: pl.solve_async_device(st.data_ptr(), eps.data_ptr(), _capi.BN_NOISE_DEVICE_T2K)
+    torch.cuda.synchronize(); pp = stamps.cpu().numpy().astype(np.float64)
+    print(f"[{noise}] pipelined launch: prologue(stage+merge+first controls) {(pp[1]-pp[0])/2400:.2f} | chunk0 {(pp[2]-pp[1])/2400:.2f} | chunks {(pp[3]-pp[2])/2400:.2f} | cost {(pp[4]-pp[3])/2400:.2f} | colsum {(pp[5]-pp[4])/2400:.2f} | total {(pp[5]-pp[0])/2400:.2f} us")
+    pl.sync()
     a = np.stack(acc[5:]).astype(np.float64)
     d = lambda i, j: np.median(a[:, j] - a[:, i]) / 2400.0      # us at 2.4 GHz
     print(f"[{noise}] rollout: prologue(stage window+mean) {d(0,1):.2f} | step0 {d(1,2):.2f} | steps 1..T-1 {d(2,3):.2f} | cost+exp {d(3,4):.2f} | column sums {d(4,5):.2f} | total {d(0,5):.2f} us")
