@@ -182,11 +182,10 @@ def main():
     # ---- headline: dependent solves of one instance per GPU -------------------------------------
     pl = settle(lambda: make_planner(inst, local), state_dev, eps_ring, kind, a.warmup, torch.cuda.synchronize)
     elapsed = timed_solves(pl, state_dev, eps_ring, kind, a.steps, sync)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                # the only collective: 8 bytes
-        elapsed = float(tmax.item())
-    value = world * a.steps / elapsed
+    from benchnav_amd.sharding import gather_throughput
+    job = gather_throughput(a.steps, elapsed, device=torch.device("cuda", local) if dist is not None else None)
+    elapsed = job["max_seconds"]                                   # the only collective: 16 bytes per rank
+    value = job["total_solves"] / elapsed
     alg_bytes = pl.algorithmic_bytes(injected_noise=(a.noise == "injected"))
     pl.close()
 
@@ -250,11 +249,17 @@ def main():
             rb, fb, _ = plb.kernel_ms()
             bytes_b = plb.algorithmic_bytes(injected_noise=(a.noise == "injected")) * B
             plb.close()
+            traffic_b = None
+            if os.path.exists(tpath):
+                try:
+                    traffic_b = json.load(open(tpath)).get(f"rollout_{a.noise}_B{B}")
+                except Exception:
+                    traffic_b = None
             out["batched"] = {"instances_per_launch": B, "value": B * nb / elb, "unit": "solves/s",
                               "ms_per_launch": elb / nb * 1e3,
                               "roofline": {"bound": "hbm", "achieved": bytes_b / (rb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": bytes_b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "kernel_ms": rb, "finish_kernel_ms": fb,
+                                           "traffic": traffic_b, "kernel_ms": rb, "finish_kernel_ms": fb,
                                            "algorithmic_bytes_per_launch": bytes_b}}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds)

@@ -17,6 +17,7 @@
 
 namespace {
 
+constexpr int kProfGroup = 10;
 thread_local std::string g_last_error;
 
 int fail(int code, const char *fmt, ...)
@@ -69,8 +70,9 @@ struct bn_mppi {
     size_t scratch_bytes = 0, eps_bytes = 0, idx_count = 0;
     float *h_pinned = nullptr;   // pinned staging for (B,3) states
     // profiling
-    std::vector<hipEvent_t> ev;  // 3 events per profiled solve: start, after rollout, after finish
-    size_t ev_used = 0;
+    std::vector<hipEvent_t> ev;  // two-launch mode: 3 events per solve (start, after rollout, after finish);
+    size_t ev_used = 0;          // pipelined mode: one event at the start of every group of kProfGroup launches
+    int prof_in_group = 0;
 };
 
 namespace {
@@ -386,8 +388,20 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     default: return fail(BN_ERR_INVALID, "unknown noise kind %d", (int)noise);
     }
 
-    const bool prof = (h->cfg.flags & BN_FLAG_PROFILE) != 0;
+    // Profiling: two-launch mode brackets each kernel with events.  In the pipelined mode a solve is ONE
+    // back-to-back launch of ~15 us; an event pair around every launch would add its own ~5 us of
+    // dispatch latency, so events are recorded every kProfGroup launches and the mean is taken per group.
+    const bool prof_grouped = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && h->pipelined;
+    const bool prof = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && !h->pipelined;
     hipEvent_t *ev = nullptr;
+    if (prof_grouped && h->prof_in_group == 0) {
+        if (h->ev_used + 1 > h->ev.size()) {
+            hipEvent_t e;
+            BN_HIP(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        BN_HIP(hipEventRecord(h->ev[h->ev_used++], h->stream));
+    }
     if (prof) {
         if (h->ev_used + 3 > h->ev.size()) {
             for (int i = 0; i < 3; ++i) {
@@ -409,7 +423,7 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
         p.have_prev = h->tail_pending ? 1 : 0;
         p.mean_from_part = h->tail_pending ? 1 : 0;
         BN_HIP(bn::launch_rollout(p, mode, h->stream));
-        if (prof) { BN_HIP(hipEventRecord(ev[1], h->stream)); BN_HIP(hipEventRecord(ev[2], h->stream)); }
+        if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
         h->tail_pending = true;
         return BN_OK;
@@ -571,6 +585,36 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!(h->cfg.flags & BN_FLAG_PROFILE)) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_PROFILE");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (h->pipelined) {
+        // close the open group with one more event *before* the flush, then average complete groups only
+        const int open = h->prof_in_group;
+        if (h->ev_used + 1 > h->ev.size()) {
+            hipEvent_t e;
+            BN_HIP(hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        BN_HIP(hipEventRecord(h->ev[h->ev_used++], h->stream));
+        if (int rc = flush_tail(h)) return rc;
+        BN_HIP(hipStreamSynchronize(h->stream));
+        const size_t marks = h->ev_used;                  // marks-1 intervals; the last one holds `open` launches (or a full group)
+        double tot = 0.0;
+        size_t launches = 0;
+        for (size_t i = 0; i + 1 < marks; ++i) {
+            const bool last = (i + 2 == marks);
+            const int in_this = (last && open != 0) ? open : kProfGroup;
+            if (last && open != 0) break;                 // skip the ragged last group
+            float a = 0.0f;
+            BN_HIP(hipEventElapsedTime(&a, h->ev[i], h->ev[i + 1]));
+            tot += a;
+            launches += in_this;
+        }
+        if (rollout_ms) *rollout_ms = launches ? (float)(tot / launches) : 0.0f;
+        if (finish_ms) *finish_ms = 0.0f;
+        if (n_solves) *n_solves = (int32_t)launches;
+        h->ev_used = 0;
+        h->prof_in_group = 0;
+        return BN_OK;
+    }
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     double r = 0.0, f = 0.0;

@@ -181,7 +181,11 @@ uint64_t bn_mppi_solve_count(const bn_mppi_t *h);
 
 /* With BN_FLAG_PROFILE: mean duration in milliseconds of the rollout kernel and of
  * the finish kernel over the solves since the last call (HIP events on the
- * handle's stream), and how many solves that covers.  Synchronises. */
+ * handle's stream), and how many solves that covers.  Synchronises.
+ * Two-launch mode: an event pair around every kernel.  Pipelined mode (one ~15 us
+ * launch per solve, back to back): one event per group of 10 launches, mean = group
+ * time / 10 (an event pair per launch would add its own dispatch latency);
+ * finish_ms is 0 there -- the tail rides inside the next launch. */
 int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t *n_solves);
 
 /* Algorithmic HBM bytes of one solve in the current mode (DESIGN.md "Roofline"). */
