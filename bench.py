@@ -69,12 +69,10 @@ def timed_solves(pl, state_dev, eps_ring, kind, steps, sync):
     sync()
     t0 = time.perf_counter()
     if eps_ring is None:
-        for _ in range(steps):
-            pl.solve_async_device(state_dev.data_ptr())
-    else:
-        n = len(eps_ring)
-        for i in range(steps):
-            pl.solve_async_device(state_dev.data_ptr(), eps_ring[i % n].data_ptr(), kind)
+        pl.solve_n_async_device(steps, state_dev.data_ptr())
+    else:                                            # eps_ring: one contiguous tensor (ring, ...), cycled per solve
+        pl.solve_n_async_device(steps, state_dev.data_ptr(), eps_ring.data_ptr(), kind, eps_ring.shape[0],
+                                eps_ring[0].numel())
     pl.flush()
     sync()
     return time.perf_counter() - t0
@@ -169,7 +167,7 @@ def main():
     state_dev = inst.start.cuda()
     if a.noise == "injected":
         gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-        eps_ring = [torch.randn(T, 2, K, device="cuda", generator=gen) for _ in range(8)]
+        eps_ring = torch.randn(8, T, 2, K, device="cuda", generator=gen)
         kind = _capi.BN_NOISE_DEVICE_T2K
     else:
         eps_ring, kind = None, _capi.BN_NOISE_PHILOX
@@ -239,7 +237,7 @@ def main():
                 return plb_
             states = torch.stack([it.start for it in insts]).cuda()
             if a.noise == "injected":
-                ring = [torch.randn(B, T, 2, K, device="cuda") for _ in range(2)]
+                ring = torch.randn(2, B, T, 2, K, device="cuda")
             else:
                 ring = None
             nb = max(50, a.steps // 10)

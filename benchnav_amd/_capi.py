@@ -48,6 +48,7 @@ SYMBOLS = {
     "bn_mppi_get_mean": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_solve": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, _FP, _FP]),
     "bn_mppi_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "bn_mppi_solve_n_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64]),
     "bn_mppi_sync": (C.c_int, [_H]),
     "bn_mppi_flush": (C.c_int, [_H]),
     "bn_mppi_get_weights": (C.c_int, [_H, C.c_int32, _FP]),

@@ -14,36 +14,32 @@ constexpr float kPi = 3.14159274101257324f;
 constexpr float kTwoPi = 6.28318548202514648f;
 
 // ---- sincos spec -------------------------------------------------------------
-// n = rint(x*2/pi); 3-term Cody-Waite reduction by pi/2 with fma; Cephes single
-// precision kernels on [-pi/4, pi/4]; compensated 1 - s/2 for the cosine.
-// Max error 1.5 ulp on |x| <= pi + 0.1 (measured against fp64).
+// n = rint(x/pi) by the add-magic trick (one fma; |x| < 1.3e7); r = x - n*pi by a 3-term Cody-Waite
+// split with fma, r in [-pi/2, pi/2]; sin(r) = r + r*s*P(s) (degree 9) and cos(r) = 1 + s*Q(s)
+// (degree 10) evaluated as one packed stream; sin(x) = (-1)^n sin(r), cos(x) = (-1)^n cos(r): one
+// shared sign flip.  Absolute error <= 1.2e-7 (positions integrate the absolute error).
+// 16 instructions.  The arithmetic (DESIGN.md "Arithmetic spec") is restated independently by the test oracle.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
 {
-    const float fn = __builtin_rintf(x * 0.636619772367581343f);
-    float r = __builtin_fmaf(-fn, 1.5703125f, x);
-    r = __builtin_fmaf(-fn, 4.837512969970703125e-4f, r);
-    r = __builtin_fmaf(-fn, 7.54978995489188216e-8f, r);
+    const float t = __builtin_fmaf(x, 0.318309886183790672f, 12582912.0f);
+    const float fn = t - 12582912.0f;
+    float r = __builtin_fmaf(-fn, 3.140625f, x);
+    r = __builtin_fmaf(-fn, 9.67502593994140625e-4f, r);
+    r = __builtin_fmaf(-fn, 1.509957990978376432e-7f, r);
     const float s = r * r;
-    // the sine (x) and cosine (y) polynomials share their shape: evaluate them as one packed stream
     const v2f s2 = {s, s};
-    v2f pq = __builtin_elementwise_fma(v2f{-1.9515295891e-4f, 2.443315711809948e-5f}, s2,
-                                       v2f{8.3321608736e-3f, -1.388731625493765e-3f});
-    pq = __builtin_elementwise_fma(pq, s2, v2f{-1.6666654611e-1f, 4.166664568298827e-2f});
-    pq = pq * s2;
-    const float S = __builtin_fmaf(pq.x, r, r);
-    const float hz = 0.5f * s;
-    const float w = 1.0f - hz;
-    const float C = w + __builtin_fmaf(pq.y, s, (1.0f - w) - hz);
-    const int n = (int)fn;
-    const bool odd = (n & 1) != 0;
-    const float a = odd ? C : S;              // |sin|-side value
-    const float b = odd ? S : C;              // |cos|-side value
-    // quadrant signs as sign-bit flips: sin negative for n&3 in {2,3}; cos negative for n&3 in {1,2}
-    const uint32_t h = (uint32_t)n << 30;     // bit 1 of n -> bit 31
-    sn = __uint_as_float(__float_as_uint(a) ^ (h & 0x80000000u));
-    cs = __uint_as_float(__float_as_uint(b) ^ ((h + 0x40000000u) & 0x80000000u));
+    // lane x: sine coefficients (one fewer: starts at SC4), lane y: cosine coefficients
+    v2f pq = {2.599125082269893e-06f, __builtin_fmaf(-2.6072027026202704e-07f, s, 2.476157715136651e-05f)};
+    pq = __builtin_elementwise_fma(pq, s2, v2f{-0.0001980613305931911f, -0.001388839678838849f});
+    pq = __builtin_elementwise_fma(pq, s2, v2f{0.008333009667694569f, 0.04166664183139801f});
+    pq = __builtin_elementwise_fma(pq, s2, v2f{-0.16666656732559204f, -0.5f});
+    const float S = __builtin_fmaf(pq.x * s, r, r);
+    const float C = __builtin_fmaf(pq.y, s, 1.0f);
+    const uint32_t sign = __float_as_uint(t) << 31;          // parity of n
+    sn = __uint_as_float(__float_as_uint(S) ^ sign);
+    cs = __uint_as_float(__float_as_uint(C) ^ sign);
 }
 
 // torch.remainder(a, b), b > 0: fmod (exact) then the divisor-sign fix.  The
@@ -66,12 +62,15 @@ __device__ __forceinline__ float wrap_angle(float th)
 
 // Same value, branch-free, valid for theta + pi in (-2 pi, 4 pi): every step after the first,
 // because the previous wrap left theta in [-pi, pi] and |trav * omega * dt| < pi (checked at create).
+// q = floor(a / 2pi) is -1, 0 or 1 there; with the multiplier fl(1/2pi_f) the rounded product lands on
+// the right side of 1 at a = 2pi_f and its predecessor, and rounding is monotone, so q is exact for every
+// float a in the interval (tests: test_near_wrap_identity).  fma(q, -2pi, a) is then
+// a - 2pi (exact, Sterbenz), a, or a + 2pi rounded once: exactly fmod plus torch.remainder's sign fix.
 __device__ __forceinline__ float wrap_angle_near(float th)
 {
     const float a = th + kPi;
-    float m = (a >= kTwoPi) ? (a - kTwoPi) : a;      // exact (Sterbenz), == fmod
-    m = (a < 0.0f) ? (a + kTwoPi) : m;               // the divisor-sign fix of torch.remainder
-    return m - kPi;
+    const float q = floorf(a * 0.15915493667125702f);
+    return __builtin_fmaf(q, -kTwoPi, a) - kPi;
 }
 
 // min(max(v, lo), hi) in one v_med3_f32 (lo <= hi)

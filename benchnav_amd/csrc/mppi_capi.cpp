@@ -440,6 +440,18 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     return BN_OK;
 }
 
+int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where, const float *eps,
+                          bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride)
+{
+    if (n < 0) return fail(BN_ERR_INVALID, "n must be >= 0");
+    if (eps && (eps_ring < 1 || eps_stride < 0)) return fail(BN_ERR_INVALID, "eps_ring must be >= 1 and eps_stride >= 0");
+    for (int32_t i = 0; i < n; ++i) {
+        const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
+        if (int rc = bn_mppi_solve_async(h, states, states_where, e, noise)) return rc;
+    }
+    return BN_OK;
+}
+
 int bn_mppi_sync(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");

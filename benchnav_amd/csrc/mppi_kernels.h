@@ -7,9 +7,10 @@
 namespace bn {
 
 constexpr int kRolloutsPerBlock = 64;   // lane = rollout; 64 rollouts per workgroup
-constexpr int kRolloutThreads = 256;    // 4 wavefronts per workgroup, specialised by role (chain / producers / consumer)
+constexpr int kRolloutThreads = 320;    // 5 wavefronts per workgroup, specialised by role (chain / 2 producers / 2 consumers)
+constexpr int kChunk = 4;                // time steps per barrier phase of the rollout kernel
 constexpr int kUPad = 65;               // LDS row pitch of the control tile (bank-conflict-free both ways)
-constexpr int kFinishThreads = 256;
+constexpr int kFinishThreads = kRolloutThreads;   // the tail runs as a stand-alone kernel or as the aux workgroup of a rollout launch
 
 enum EpsMode : int { kEpsPhilox = 0, kEpsKT2 = 1, kEpsT2K = 2 };
 

@@ -24,7 +24,7 @@ namespace bn {
 
 namespace {
 
-constexpr int TU = 4;   // time steps per software-pipelined chunk (noise is fetched one chunk ahead)
+constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chunk c, consumers on c-1, producers on c+2
 
 // Timing ablations for tools/ablate.py (never set in the shipped library): bit 0 skip stage cost,
 // 1 skip fp64 accumulation, 2 skip X stores, 3 skip control tile + control cost, 4 skip sincos,
@@ -112,19 +112,17 @@ __device__ __forceinline__ float trav_lookup(const SolveParams &p, const float *
 template <int GEO>
 __device__ __forceinline__ float trav_window(const SolveParams &p, const float *win, const Win w, float x, float y)
 {
-    float qx, qy;
+    v2f q;
+    const v2f xy = {x, y}, ir = {p.inv_res, p.inv_res}, nw = {-w.fx0, -w.fy0};
     if (GEO == kGeoPow2Origin0) {
-        qx = __builtin_fmaf(x, p.inv_res, -w.fx0);
-        qy = __builtin_fmaf(y, p.inv_res, -w.fy0);
+        q = __builtin_elementwise_fma(xy, ir, nw);                      // one v_pk_fma_f32
     } else if (GEO == kGeoPow2) {
-        qx = __builtin_fmaf(x - p.x0, p.inv_res, -w.fx0);
-        qy = __builtin_fmaf(y - p.y0, p.inv_res, -w.fy0);
+        q = __builtin_elementwise_fma(xy - v2f{p.x0, p.y0}, ir, nw);
     } else {
-        qx = (x - p.x0) / p.res - w.fx0;
-        qy = (y - p.y0) / p.res - w.fy0;
+        q = v2f{(x - p.x0) / p.res, (y - p.y0) / p.res} + nw;
     }
-    const float li = clampf(floorf(qx), 0.0f, w.fwm1);
-    const float lj = clampf(floorf(qy), 0.0f, w.fwm1);
+    const float li = clampf(floorf(q.x), 0.0f, w.fwm1);
+    const float lj = clampf(floorf(q.y), 0.0f, w.fwm1);
     return win[(int)__builtin_fmaf(lj, w.fwn, li)];
 }
 
@@ -142,8 +140,10 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
 {
     const float tv = c.trav * u0;
     tn = c.th + (c.trav * u1) * p.dt;                                  // :88
-    xn = c.x + (tv * c.cs) * p.dt;                                     // :86
-    yn = c.y + (tv * c.sn) * p.dt;                                     // :87
+    // x and y advance in lockstep: packed multiply / multiply / add (same roundings as the scalar form)
+    const v2f pos = v2f{c.x, c.y} + (v2f{tv, tv} * v2f{c.cs, c.sn}) * v2f{p.dt, p.dt};   // :86-87
+    xn = pos.x;
+    yn = pos.y;
     if (BN_ABLATE & 64) c.th = tn; else
     c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);               // :90
     c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
@@ -154,6 +154,9 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     c.trav = LDSWIN ? trav_window<GEO>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
 }
 
+// Wave-wide butterfly reductions (ds_bpermute).  A DPP row-scan formulation was measured 0.25 us faster
+// per launch but hipcc's DPP combiner mis-folds the update_dpp + add pairs inside this kernel (wrong sums
+// on hardware, correct in an isolated test kernel), so the shuffle form stays.
 __device__ __forceinline__ float wave_max(float v)
 {
 #pragma unroll
@@ -188,31 +191,43 @@ __device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool
 // which is what lets each rollout block of the next solve recompute the warm-start mean on its own.
 // LDS scratch: sc[nblk], red[4].  Returns (max z, sum exp) for the weights.
 constexpr int kMergePrefetch = 16;
+struct MergeLoads { float v[kMergePrefetch]; float mi, si; int j; };
+
+// Issue every load of the few-blocks merge (nblk <= 64) without consuming any: lets the caller put
+// other memory traffic (the window staging) in flight underneath.
+__device__ __forceinline__ MergeLoads merge_issue(const float *__restrict__ part, int nblk, int T, int tid)
+{
+    const int PS = 2 + 2 * T;
+    const int lane = tid & 63;
+    MergeLoads L;
+    L.j = tid < 2 * T ? tid : 0;
+#pragma unroll
+    for (int i = 0; i < kMergePrefetch; ++i) L.v[i] = part[(size_t)min(i, nblk - 1) * PS + 2 + L.j];
+    const bool has = lane < nblk;
+    L.mi = has ? part[(size_t)lane * PS] : -INFINITY;
+    L.si = has ? part[(size_t)lane * PS + 1] : 0.0f;
+    return L;
+}
+
 __device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
-                                               float *red, int tid, float &m_out, float &S_out)
+                                               float *red, int tid, float &m_out, float &S_out, const MergeLoads *pre)
 {
     const int PS = 2 + 2 * T;
     const int lane = tid & 63;
     float m, S;
     if (nblk <= 64) {
-        // Few blocks (K <= 4096): every wave reduces the nblk (max, sum) pairs itself with shuffles --
-        // same inputs, same operations, so all waves (and all workgroups) hold identical m, S and
-        // scales -- and all loads are issued before the first use: one memory round trip, one barrier.
-        const int j = tid < 2 * T ? tid : 0;
-        float v[kMergePrefetch];
-#pragma unroll
-        for (int i = 0; i < kMergePrefetch; ++i) v[i] = part[(size_t)min(i, nblk - 1) * PS + 2 + j];
-        const bool has = lane < nblk;
-        const float mi = has ? part[(size_t)lane * PS] : -INFINITY;
-        const float si = has ? part[(size_t)lane * PS + 1] : 0.0f;
-        m = wave_max(mi);
-        const float f = has ? expf(mi - m) : 0.0f;       // scale of block `lane`; 0 past nblk
-        S = wave_sum(si * f);
+        // Few blocks (K <= 4096): every wave reduces the nblk (max, sum) pairs itself -- same inputs,
+        // same operations, so all waves (and all workgroups) hold identical m, S and scales -- and all
+        // loads are issued before the first use: one memory round trip, one barrier.
+        const MergeLoads L = pre ? *pre : merge_issue(part, nblk, T, tid);
+        m = wave_max(L.mi);
+        const float f = lane < nblk ? expf(L.mi - m) : 0.0f;       // scale of block `lane`; 0 past nblk
+        S = wave_sum(L.si * f);
         for (int jj = tid; jj < 2 * T; jj += kFinishThreads) {
             float acc = 0.0f;
-            if (jj == j) {
+            if (jj == L.j) {
 #pragma unroll
-                for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(v[i], __shfl(f, i), acc);   // f == 0 past nblk
+                for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], __shfl(f, i), acc);   // f == 0 past nblk
                 for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], __shfl(f, i), acc);
             } else {
                 for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], __shfl(f, i), acc);
@@ -268,7 +283,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     BN_STAMP(9);
 
     float m, S;
-    merge_partials(part, nblk, T, us, sc, red, tid, m, S);
+    merge_partials(part, nblk, T, us, sc, red, tid, m, S, nullptr);
     for (int j = tid; j < 2 * T; j += kFinishThreads) {
         p.ustar[(size_t)b * 2 * T + j] = us[j];
         p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
@@ -289,7 +304,18 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         float xn, yn, tn;
         chain_step<GEO, LDSWIN, true>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
         Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
-        for (int t = 1; t < T; ++t) {
+        int t = 1;
+        for (; t + 4 <= T; t += 4) {                       // controls of four steps read up front (LDS latency off the chain)
+            float uq[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                chain_step<GEO, LDSWIN, false>(p, win, map, w, c, uq[i][0], uq[i][1], xn, yn, tn);
+                Xs[3 * (t + i) + 0] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
+            }
+        }
+        for (; t < T; ++t) {
             chain_step<GEO, LDSWIN, false>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn);
             Xs[3 * t + 0] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
         }
@@ -346,19 +372,21 @@ __device__ __forceinline__ void produce_pair(const SolveParams &p, const float *
 }
 
 // ------------------------------------------------------------------------------
-// Rollout + cost kernel.  grid = (ceil(K/64), B), block = 256 = 4 wavefronts that all map
+// Rollout + cost kernel.  grid = (ceil(K/64) [+1 aux], B), block = 320 = 5 wavefronts that all map
 // lane -> rollout k = 64*blockIdx.x + lane and split the work of those 64 rollouts by ROLE,
-// because one wavefront issues at most one instruction every ~4.5-6.5 cycles (measured,
-// tools/ubench.hip) and the T-step recurrence is a serial instruction chain:
-//   wave 0  chain     the recurrence only: transit + gather (chain_step), ~60 instructions/step
-//   wave 1  producer  noise -> clamped controls for the first half of chunk c+2
-//   wave 3  producer  ... second half of chunk c+2
-//   wave 2  consumer  chunk c-1: trajectory stores, control cost, stage cost, fp64 accumulation
+// because one wavefront issues one instruction every ~5 cycles whether or not it depends on the
+// previous one (measured, tools/ubench2.hip: no intra-wave overlap) and the T-step recurrence is a
+// serial instruction chain:
+//   wave 0  chain      the recurrence only: transit + gather (chain_step), ~50 instructions/step
+//   wave 1  producer   noise -> clamped controls for the first half of chunk c+2
+//   wave 2  producer   ... second half of chunk c+2
+//   wave 3  consumer A chunk c-1: trajectory stores, control cost (fp64 accumulation in step order)
+//   wave 4  consumer B chunk c-1: stage cost (sqrt, collision flag; fp64 accumulation in step order)
 // Chunks are TU = 4 steps; one LDS-only barrier per chunk hands the control tile forward and the
-// chain's outputs (ring of 2 chunks) backward.  The per-rollout sums are accumulated by one wave in
+// chain's outputs (ring of 2 chunks) backward.  Each per-rollout sum is accumulated by one wave in
 // step order, so the arithmetic is identical to a single sequential loop (Arithmetic spec).
-// LDS: [ window WN*WN | mean 2T | mean*inv_var 2T | control tile 2T x 65 | ring 2 x TU x 4 x 64 |
-//        final state 4 x 64 | e 64 ]
+// LDS: [ ring 2 x TU x 64 x float4 | final state + control-cost sum 5 x 64 | e 64 | window WN*WN | mean 2T | mean*inv_var 2T |
+//        control tile 2T x 65 ]
 // ------------------------------------------------------------------------------
 template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
 __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolveParams p)
@@ -371,16 +399,19 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
         return;
     }
     const int T = p.T, K = p.K;
-    float *win = smem;
+    float *ring = smem;                               // first: 16-byte aligned for the b128 ring accesses
+    float *fin = ring + 2 * TU * 4 * 64;
+    float *el = fin + 5 * 64;
+    float *win = el + 64;
     float *ml = win + (LDSWIN ? p.WN * p.WN : 0);
     float *mv = ml + 2 * T;
     float *Ul = mv + 2 * T;
-    float *ring = Ul + 2 * T * kUPad;
-    float *fin = ring + 2 * TU * 4 * 64;
-    float *el = fin + 4 * 64;
 
     const int tid = threadIdx.x;
-    const int wv = tid >> 6, lane = tid & 63;
+    const int wid = tid >> 6, lane = tid & 63;
+    // A workgroup's waves are dealt to the 4 SIMDs cyclically, so waves 0 and 4 share one: they get the two
+    // light consumer roles; the chain (role 0) has a SIMD to itself.  role: 0 chain, 1-2 producers, 3-4 consumers.
+    const int wv = (wid == 0) ? 3 : (wid == 4) ? 4 : wid - 1;
     const int b = blockIdx.y;
     const int k = blockIdx.x * kRolloutsPerBlock + lane;
     const bool active = k < K;
@@ -393,17 +424,22 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     const uint64_t solve = p.solve;
     BN_STAMP(0);
 
+    // warm start straight from the previous solve's per-block statistics (bit-identical to the U* the aux
+    // block publishes): no kernel boundary between consecutive solves of one instance.  Its loads go out
+    // first so that they and the window staging (which waits for the state) share one memory round trip.
+    const float *part_prev = p.part_prev + (size_t)b * p.nblk * (2 + 2 * T);
+    MergeLoads pre;
+    const bool pre_ok = p.mean_from_part && p.nblk <= 64;
+    if (pre_ok) pre = merge_issue(part_prev, p.nblk, T, tid);
+
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN) {
         w = window_origin<GEO>(p, sx, sy);
         stage_window(win, map, w, p.WN, p.G, tid, kRolloutThreads);
     }
     if (p.mean_from_part) {
-        // warm start straight from the previous solve's per-block statistics (bit-identical to the U*
-        // the aux block publishes): no kernel boundary between consecutive solves of one instance
         float m_unused, S_unused;
-        merge_partials(p.part_prev + (size_t)b * p.nblk * (2 + 2 * T), p.nblk, T, ml, ring, ring + p.nblk, tid,
-                       m_unused, S_unused);
+        merge_partials(part_prev, p.nblk, T, ml, ring, ring + p.nblk, tid, m_unused, S_unused, pre_ok ? &pre : nullptr);
         for (int j = tid; j < 2 * T; j += kRolloutThreads) mv[j] = ml[j] * ((j & 1) ? p.iv1 : p.iv0);
     } else {
         for (int j = tid; j < 2 * T; j += kRolloutThreads) {
@@ -421,44 +457,60 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
     float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
 
-    // controls of chunks 0 and 1 (steps 0..7): two steps per wave
-    if (2 * wv < T) produce_pair<EPS, STORE_U>(p, eps, b, kk, 2 * wv, solve, ml, Ul, Ub, Kp, lane);
+    // controls of chunks 0 and 1 (steps 0 .. 2*TU-1): TU/2 steps per wave (waves 0-3)
+    if (wid < 4) {
+#pragma unroll
+        for (int q = 0; q < TU / 4; ++q) {
+            const int t = wid * (TU / 2) + 2 * q;
+            if (t < T) produce_pair<EPS, STORE_U>(p, eps, b, kk, t, solve, ml, Ul, Ub, Kp, lane);
+        }
+    }
     BN_BAR();
     BN_STAMP(1);
 
     Chain c;                                          // wave 0
-    double Sd = 0.0, Ad = 0.0;                        // wave 2: fp64 accumulation of the fp32 terms (Arithmetic spec)
+    double Sd = 0.0, Ad = 0.0;                        // waves 4 / 3: fp64 accumulation of the fp32 terms (Arithmetic spec)
     if (wv == 0) {
         c.x = sx; c.y = sy; c.th = sth;               // mppi.py:160
         sincos_spec(c.th, c.sn, c.cs);
         c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
     }
 
-    // wave 0: one chain step; emits what the reference leaves in slot t plus the traversability of state t+1
-#define BN_CHAIN(FIRST, t, slot)                                                                               \
+    // wave 0: one chain step; emits what the reference leaves in slot t plus the traversability of state t+1.
+    // The controls of the whole chunk are read from the LDS tile up front (uc[]): the compiler cannot hoist
+    // those reads over the ring writes itself, and a 64-cycle LDS round trip per step would sit on the chain.
+    // The ring writes come last (sched_barrier) so the wait for the gather overlaps the rest of the step.
+#define BN_CHAIN(FIRST, i, slot)                                                                               \
     do {                                                                                                       \
-        const float u0 = Ul[(2 * (t)) * kUPad + lane], u1 = Ul[(2 * (t) + 1) * kUPad + lane];                  \
         float xn, yn, tn;                                                                                      \
-        chain_step<GEO, LDSWIN, FIRST>(p, win, map, w, c, u0, u1, xn, yn, tn);                                 \
-        float *o = (slot) + lane;                                                                              \
-        o[0] = xn; o[64] = yn; o[128] = tn; o[192] = c.trav;                                                   \
+        chain_step<GEO, LDSWIN, FIRST>(p, win, map, w, c, uc[i][0], uc[i][1], xn, yn, tn);                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        reinterpret_cast<float4 *>(slot)[lane] = make_float4(xn, yn, tn, c.trav);   /* one ds_write_b128 */     \
     } while (0)
 
-    // wave 2: everything per step that is not on the recurrence
-#define BN_CONSUME(t, slot)                                                                                    \
+    // wave 3: trajectory stores and control cost of one step
+#define BN_CONSUME_A(t, o)                                                                                     \
     do {                                                                                                       \
-        const float *o = (slot) + lane;                                                                        \
-        const float xn = o[0], yn = o[64], tn = o[128], trn = o[192];                                          \
+        if (!(BN_ABLATE & 4)) {                                                                                \
         float *Xt = Xb + (size_t)(3 * (t)) * Kp;         /* slot t keeps the un-clamped state (aliasing) */     \
-        Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                              \
+        Xt[0] = o.x; Xt[Kp] = o.y; Xt[2 * Kp] = o.z;                                                           \
+        } else { BN_KEEP(o.z); }                                                                               \
+        if (!(BN_ABLATE & 8)) {                                                                                \
         const float u0 = Ul[(2 * (t)) * kUPad + lane], u1 = Ul[(2 * (t) + 1) * kUPad + lane];                  \
         const float a = mv[2 * (t)] * u0 + mv[2 * (t) + 1] * u1;            /* mppi.py:178-182 */             \
         Ad += (double)(p.lambda_ * a);                                                                         \
-        /* the cell of the un-clamped slot equals the cell of the clamped state (index clamp,               */ \
-        /* grid_map.py:209), so the chain's gather serves stage cost t and transit t+1                      */ \
-        const float dx = xn - gx, dy = yn - gy;                                                                \
-        const float sc = sqrtf(dx * dx + dy * dy) + (trn <= p.thr ? 1.0e4f : 0.0f);   /* objectives.py:47-53 */ \
+        }                                                                                                      \
+    } while (0)
+
+    // wave 4: stage cost of one step.  The cell of the un-clamped slot equals the cell of the clamped
+    // state (index clamp, grid_map.py:209), so the chain's gather serves stage cost t and transit t+1.
+#define BN_CONSUME_B(t, o)                                                                                     \
+    do {                                                                                                       \
+        if (BN_ABLATE & 1) { BN_KEEP(o.x); BN_KEEP(o.y); BN_KEEP(o.w); } else {                                \
+        const float dx = o.x - gx, dy = o.y - gy;                                                              \
+        const float sc = sqrtf(dx * dx + dy * dy) + (o.w <= p.thr ? 1.0e4f : 0.0f);   /* objectives.py:47-53 */ \
         Sd += (double)sc;                                                                                      \
+        }                                                                                                      \
     } while (0)
 
     // One phase = one chunk of TU steps for the chain, the previous chunk for the consumer, the
@@ -468,25 +520,39 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
         if (wv == 0) {                                                                                         \
             if ((cc) * TU < T) {                                                                               \
                 float *slot = ring + (((cc) & 1) * TU) * 256;                                                  \
+                float uc[TU][2];                                                                               \
+                _Pragma("unroll") for (int i = 0; i < TU; ++i) {                                               \
+                    const int t = min((cc) * TU + i, T - 1);                                                   \
+                    uc[i][0] = Ul[(2 * t) * kUPad + lane];                                                     \
+                    uc[i][1] = Ul[(2 * t + 1) * kUPad + lane];                                                 \
+                }                                                                                              \
                 _Pragma("unroll") for (int i = 0; i < TU; ++i) {                                               \
                     const int t = (cc) * TU + i;                                                               \
                     if (!(GUARD) || t < T) {                                                                   \
-                        if ((FIRSTCHUNK) && i == 0) BN_CHAIN(true, t, slot + i * 256);                         \
-                        else BN_CHAIN(false, t, slot + i * 256);                                               \
+                        if ((FIRSTCHUNK) && i == 0) BN_CHAIN(true, i, slot + i * 256);                         \
+                        else BN_CHAIN(false, i, slot + i * 256);                                               \
                     }                                                                                          \
                 }                                                                                              \
             }                                                                                                  \
-        } else if (wv == 2) {                                                                                  \
+        } else if (wv >= 3) {                                                                                  \
             if ((cc) >= 1) {                                                                                   \
                 const float *slot = ring + ((((cc) - 1) & 1) * TU) * 256;                                      \
+                float4 rq[TU];                        /* the whole chunk in one burst of ds_read_b128 */      \
+                _Pragma("unroll") for (int i = 0; i < TU; ++i)                                                 \
+                    rq[i] = reinterpret_cast<const float4 *>(slot + i * 256)[lane];                            \
                 _Pragma("unroll") for (int i = 0; i < TU; ++i) {                                               \
                     const int t = ((cc) - 1) * TU + i;                                                         \
-                    if (!(GUARD) || t < T) BN_CONSUME(t, slot + i * 256);                                      \
+                    if (!(GUARD) || t < T) {                                                                   \
+                        if (wv == 3) BN_CONSUME_A(t, rq[i]);                                                   \
+                        else BN_CONSUME_B(t, rq[i]);                                                           \
+                    }                                                                                          \
                 }                                                                                              \
             }                                                                                                  \
         } else {                                                                                               \
-            const int t = ((cc) + 2) * TU + (wv == 1 ? 0 : 2);                                                 \
-            if (t < T) produce_pair<EPS, STORE_U>(p, eps, b, kk, t, solve, ml, Ul, Ub, Kp, lane);              \
+            _Pragma("unroll") for (int q = 0; q < TU / 4; ++q) {                                               \
+                const int t = ((cc) + 2) * TU + (wv == 1 ? 0 : TU / 2) + 2 * q;                                \
+                if (t < T) produce_pair<EPS, STORE_U>(p, eps, b, kk, t, solve, ml, Ul, Ub, Kp, lane);          \
+            }                                                                                                  \
         }                                                                                                      \
     } while (0)
 
@@ -495,31 +561,47 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     BN_BAR();
     BN_STAMP(2);
     int cc = 1;
+#ifdef BN_TIMING
+    unsigned long long busy = 0;
+#endif
     for (; cc < nfull; ++cc) {                        // steady state: chunks cc (chain) and cc-1 (consumer) are full
+#ifdef BN_TIMING
+        const unsigned long long t_a = __builtin_readcyclecounter();
+#endif
         BN_PHASE(cc, false, false);
+#ifdef BN_TIMING
+        busy += __builtin_readcyclecounter() - t_a;
+#endif
         BN_BAR();
     }
+#ifdef BN_TIMING
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) p.stamps[16 + wv] = busy;
+#endif
     for (; cc * TU < T + TU; ++cc) {                  // ragged tail and the consumer's drain
         BN_PHASE(cc, false, true);
         BN_BAR();
     }
 #undef BN_PHASE
-#undef BN_CONSUME
+#undef BN_CONSUME_A
+#undef BN_CONSUME_B
 #undef BN_CHAIN
     BN_STAMP(3);
 
     if (wv == 0) {                                     // state T (clamped / wrapped) and its traversability
         fin[lane] = c.x; fin[64 + lane] = c.y; fin[128 + lane] = c.th; fin[192 + lane] = c.trav;
+    } else if (wv == 3) {
+        fin[256 + lane] = (float)Ad;                   // sum_t lambda * control cost, rounded once
     }
     BN_BAR();
 
-    if (wv == 2) {
-        const float xT = fin[lane], yT = fin[64 + lane], thT = fin[128 + lane], trT = fin[192 + lane];
+    if (wv == 3) {
         float *Xt = Xb + (size_t)(3 * T) * Kp;         // slot T: clamped / wrapped state
-        Xt[0] = xT; Xt[Kp] = yT; Xt[2 * Kp] = thT;
+        Xt[0] = fin[lane]; Xt[Kp] = fin[64 + lane]; Xt[2 * Kp] = fin[128 + lane];
+    } else if (wv == 4) {
+        const float xT = fin[lane], yT = fin[64 + lane], trT = fin[192 + lane], A = fin[256 + lane];
         const float dxT = xT - gx, dyT = yT - gy;
         const float term = sqrtf(dxT * dxT + dyT * dyT) + (trT <= p.thr ? 1.0e4f : 0.0f);    // mppi.py:184
-        const float cost = ((float)Sd + term) + (float)Ad;                                     // mppi.py:186-190
+        const float cost = ((float)Sd + term) + A;                                             // mppi.py:186-190
         if (active) p.cost[(size_t)b * K + k] = cost;
         // block-local softmin statistics   mppi.py:193-199
         const float z = active ? (-cost) / p.lambda_ : -INFINITY;
@@ -534,7 +616,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     }
     BN_BAR();
     BN_STAMP(4);
-    {   // weighted control sums of this block: column j of the tile, 4 waves x 64 lanes over 2T columns
+    {   // weighted control sums of this block: column j of the tile, 5 waves x 64 lanes over 2T columns
         float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
         for (int j = tid; j < 2 * T; j += kRolloutThreads) {
             const float *col = Ul + j * kUPad;
@@ -652,7 +734,7 @@ hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
 
 size_t rollout_lds_bytes(const SolveParams &p)
 {
-    return sizeof(float) * ((size_t)p.WN * p.WN + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad + 2 * 4 * 4 * 64 + 4 * 64 + 64);
+    return sizeof(float) * ((size_t)p.WN * p.WN + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad + 2 * kChunk * 4 * 64 + 5 * 64 + 64);
 }
 
 size_t finish_lds_bytes(const SolveParams &p)

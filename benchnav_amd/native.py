@@ -120,6 +120,12 @@ class NativeMPPI:
         _capi.check(self._lib.bn_mppi_solve_async(self._h, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
                                                   C.c_void_p(eps_ptr), kind))
 
+    def solve_n_async_device(self, n: int, state_ptr: int, eps_ptr: Optional[int] = None,
+                             kind: int = _capi.BN_NOISE_PHILOX, eps_ring: int = 1, eps_stride: int = 0):
+        """Enqueue n dependent (warm-started) solves from one C call: no per-launch Python overhead."""
+        _capi.check(self._lib.bn_mppi_solve_n_async(self._h, n, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
+                                                    C.c_void_p(eps_ptr), kind, eps_ring, eps_stride))
+
     def sync(self):
         """Write the pending tail of the latest solve and wait for the stream."""
         _capi.check(self._lib.bn_mppi_sync(self._h))

@@ -148,6 +148,11 @@ int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, c
  * bn_mppi_device_buffer are up to date after bn_mppi_sync (or bn_mppi_flush + stream order). */
 int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where,
                         const float *eps, bn_noise_kind noise);
+/* n dependent solves enqueued from one call (the warm start chains them on the device; the state is
+ * re-read from `states` by every solve, so a device-resident state may be advanced in between by
+ * other work on the same stream).  Noise block i is eps + (i % eps_ring) * eps_stride floats. */
+int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
+                          const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
 int bn_mppi_sync(bn_mppi_t *h);
 /* Enqueue the pending tail (if any) without waiting. */
 int bn_mppi_flush(bn_mppi_t *h);

@@ -17,7 +17,7 @@ inst = synth.make_instance(256, seed=0)
 for noise in ("philox", "t2k"):
     pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, stream=0)
     pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
-    stamps = torch.zeros(16, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(32, dtype=torch.int64, device="cuda")
     pl._lib.bn_mppi_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
     pl._lib.bn_mppi_debug_set_stamps(pl._h, C.c_void_p(stamps.data_ptr()))
     st = inst.start.cuda(); eps = torch.randn(50, 2, 1024, device="cuda"); torch.cuda.synchronize()
@@ -32,6 +32,7 @@ for noise in ("philox", "t2k"):
         else: pl.solve_async_device(st.data_ptr(), eps.data_ptr(), _capi.BN_NOISE_DEVICE_T2K)
     torch.cuda.synchronize(); pp = stamps.cpu().numpy().astype(np.float64)
     print(f"[{noise}] pipelined launch: prologue(stage+merge+first controls) {(pp[1]-pp[0])/2400:.2f} | chunk0 {(pp[2]-pp[1])/2400:.2f} | chunks {(pp[3]-pp[2])/2400:.2f} | cost {(pp[4]-pp[3])/2400:.2f} | colsum {(pp[5]-pp[4])/2400:.2f} | total {(pp[5]-pp[0])/2400:.2f} us")
+    print(f"[{noise}]   busy us per role in the steady-state loop (chain, producer, producer, consumer A, consumer B):", " ".join(f"{pp[16+i]/2400:.2f}" for i in range(5)))
     pl.sync()
     a = np.stack(acc[5:]).astype(np.float64)
     d = lambda i, j: np.median(a[:, j] - a[:, i]) / 2400.0      # us at 2.4 GHz
