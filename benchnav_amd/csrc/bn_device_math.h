@@ -100,16 +100,19 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
     return c;
 }
 
-// Two independent standard normals from two 32-bit words.
+// Two independent standard normals from two 32-bit words (Box-Muller).  This is the library's own noise
+// stream, not part of the parity spec, so it uses the hardware transcendentals: v_log_f32, v_sqrt_f32 and
+// v_sin_f32 / v_cos_f32 (which take their argument in revolutions, so 2*pi*u2 is never formed).  ~14
+// instructions per pair instead of ~50 with the precise library forms; bn_mppi_get_philox_noise regenerates
+// the identical values with the same instructions.
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
 {
     const float u1 = (float)(a >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;  // (0,1)
     const float u2 = (float)(b >> 8) * 5.9604644775390625e-8f;                            // [0,1)
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincos_spec(kTwoPi * u2, sn, cs);
-    z0 = rad * cs;
-    z1 = rad * sn;
+    // -2 ln u1 = (-2 ln 2) * log2(u1)
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    z0 = rad * __builtin_amdgcn_cosf(u2);
+    z1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
 // The library's own noise stream (BN_NOISE_PHILOX): one Philox block per (instance b, rollout k,

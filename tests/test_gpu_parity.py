@@ -125,6 +125,51 @@ def test_ragged_and_tiny_sizes_against_oracle(K, T, G, res):
         assert_oracle_parity(oracle_metrics(native_outputs(pl, us, xs), orc), ctx=f"K={K} T={T}")
 
 
+@pytest.mark.parametrize("res,x_lim,y_lim", [(0.5, (-4.0, 12.0), (3.0, 19.0)), (0.3, (-2.4, 7.2), (1.5, 11.1))],
+                         ids=["pow2-res-shifted-origin", "general-res-shifted-origin"])
+def test_shifted_origin_geometry_against_oracle(res, x_lim, y_lim):
+    """x/y_limits whose lower bound is not 0: the index origin and the lower clamp move with it
+    (grid_map.py:199-201, robot_model.py:93-94); exercises the kGeoPow2 and kGeoGeneral kernels."""
+    O = _oracle()
+    from benchnav_amd import NativeMPPI
+    K, T, G = 200, 24, 32
+    rng = np.random.default_rng(11)
+    R = (rng.random((G, G)) * 0.9).astype(np.float32)
+    state = np.array([x_lim[0] + 0.2, y_lim[1] - 0.3, 2.2], np.float32)        # near a corner: clamps on both axes
+    goal = np.array([x_lim[0] + 9.0, y_lim[0] + 5.0], np.float32)
+    eps = rng.standard_normal((K, T, 2)).astype(np.float32)
+    p = O.make_params(K, T, G, res, goal, x_limits=x_lim, y_limits=y_lim, trig=O.TRIG_SPEC)
+    orc = O.solve(p, R, state, np.zeros((T, 2), np.float32), eps)
+    for lds in (True, False):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=res, x_limits=x_lim, y_limits=y_lim,
+                        store_controls=True, lds_window=lds) as pl:
+            pl.set_map(R); pl.set_goal(goal)
+            us, xs = pl.solve(state, eps)
+            assert_oracle_parity(oracle_metrics(native_outputs(pl, us, xs), orc), ctx=f"res={res} lds={lds}")
+
+
+def test_solve_n_async_equals_a_python_loop():
+    import torch
+    from benchnav_amd import _capi
+    fx = load_case("c1_stuck")
+    ring = torch.from_numpy(np.random.default_rng(5).standard_normal((3, int(fx["T"]), 2, int(fx["K"]))).astype(np.float32)).cuda()
+    st = torch.tensor(fx["state_0"], device="cuda")
+    torch.cuda.synchronize()
+    out = []
+    for use_n in (True, False):
+        with native_planner_for(fx) as pl:
+            pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
+            if use_n:
+                pl.solve_n_async_device(7, st.data_ptr(), ring.data_ptr(), _capi.BN_NOISE_DEVICE_T2K, 3, ring[0].numel())
+            else:
+                for i in range(7):
+                    pl.solve_async_device(st.data_ptr(), ring[i % 3].data_ptr(), _capi.BN_NOISE_DEVICE_T2K)
+            pl.sync()
+            out.append((pl.states(), pl.weights(), pl.get_mean()))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
+
 def test_zero_sigma_gives_uniform_weights_and_mean_controls():
     from benchnav_amd import NativeMPPI
     K, T, G = 256, 12, 32
