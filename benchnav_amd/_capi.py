@@ -20,6 +20,7 @@ BN_MEM_HOST, BN_MEM_DEVICE = 0, 1
  BN_BUF_MEAN, BN_BUF_MAP, BN_BUF_GOAL) = range(9)
 BN_FLAG_STORE_CONTROLS, BN_FLAG_SHARED_MAP, BN_FLAG_NO_LDS_WINDOW, BN_FLAG_PROFILE, BN_FLAG_PRIVATE_STREAM = 1, 2, 4, 8, 16
 BN_FLAG_NO_PIPELINE = 32
+BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
 ABI_VERSION = 1
 
 
@@ -62,6 +63,9 @@ SYMBOLS = {
     "bn_mppi_row_pitch": (C.c_int32, [_H]),
     "bn_mppi_kernel_ms": (C.c_int, [_H, _FP, _FP, C.POINTER(C.c_int32)]),
     "bn_mppi_algorithmic_bytes": (C.c_int64, [_H, C.c_int]),
+    "bn_risk_map_infer": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_float,
+                                    C.c_int32, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]),
+    "bn_risk_last_error": (C.c_char_p, []),
     "bn_last_error": (C.c_char_p, []),
     "bn_mppi_abi_version": (C.c_int, []),
 }

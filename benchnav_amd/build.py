@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbenchnav_mppi.so")
-SOURCES = ["mppi_kernels.hip", "mppi_capi.cpp"]
+SOURCES = ["mppi_kernels.hip", "mppi_capi.cpp", "risk_kernels.hip"]
 HEADERS = ["mppi_kernels.h", "bn_device_math.h", os.path.join("..", "..", "include", "benchnav_mppi.h")]
 
 # -ffp-contract=off: the arithmetic spec fixes where FMAs are (explicit __builtin_fmaf only).

@@ -196,6 +196,23 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
 /* Algorithmic HBM bytes of one solve in the current mode (DESIGN.md "Roofline"). */
 int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise);
 
+/*
+ * TraversabilityModel._infer_risk_map, traversability_model.py:28-51 (runs once per dynamics object, in
+ * UnicycleModel.__init__): the (G,G) risk map from the predicted slip distribution Normal(mean, std).
+ *   BN_RISK_EXPECTED  mean                                             (:30-31)
+ *   BN_RISK_VAR       torch.quantile(samples, confidence, dim=0)       (:33-36), linear interpolation
+ *   BN_RISK_CVAR      nanmean of the samples strictly above that       (:37-42)
+ * samples_i = mean + std * z_i; z = (num_samples, G, G) standard normals supplied by the caller (the
+ * reference's Normal.sample stream, for parity) or NULL: generated in the kernel (Philox, keyed by seed).
+ * Stateless; host-resident arguments are copied and the call synchronises, device-resident ones are only
+ * enqueued on `stream`.  Errors: bn_risk_last_error().
+ */
+typedef enum bn_risk_metric { BN_RISK_EXPECTED = 0, BN_RISK_VAR = 1, BN_RISK_CVAR = 2 } bn_risk_metric;
+int bn_risk_map_infer(int32_t device_id, void *stream, const float *mean, const float *std, bn_mem_kind where_in,
+                      int32_t grid_size, bn_risk_metric metric, float confidence, int32_t num_samples,
+                      const float *z, bn_mem_kind where_z, uint64_t seed, float *out, bn_mem_kind where_out);
+const char *bn_risk_last_error(void);
+
 const char *bn_last_error(void);
 int bn_mppi_abi_version(void);
 

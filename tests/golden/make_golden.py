@@ -123,8 +123,36 @@ def run_case(name, *, G, res, K, T, risk_mean, risk_std=None, metric="expected_v
           f"max_w={float(solver._weights.max()):.3f} -> {nbytes/1024:.0f} KiB")
 
 
+def run_riskmap_case():
+    """Risk-map precompute (traversability_model.py:28-51): the reference's var / cvar maps for a known z."""
+    from src.simulator.problem_formulation.traversability_model import TraversabilityModel
+    G, n = 24, 200
+    mean_map = smooth_risk_map(G, 7) * 0.7
+    std_map = slip_std_map(G, 7)
+    out = dict(G=G, n=n, mean=mean_map.numpy(), std=std_map.numpy(), torch_version=torch.__version__)
+    for metric, q in (("var", 0.9), ("cvar", 0.9), ("var", 0.5), ("cvar", 0.975)):
+        tens = {"heights": torch.zeros(G, G), "slopes": torch.zeros(G, G), "t_classes": torch.zeros(G, G), "colors": torch.zeros(3, G, G)}
+        dist = {"latent_models": Normal(mean_map, std_map), "predictions": Normal(mean_map, std_map)}
+        gm = GridMap(grid_size=G, resolution=0.5, tensors=tens, distributions=dist, instance_name="synthetic", device="cpu")
+        cfg = ModelConfig(mode="inference", inference_metric=metric, confidence_value=q)
+        tm = TraversabilityModel.__new__(TraversabilityModel)      # skip __init__'s own (default-size) inference
+        tm._grid_map, tm._model_config = gm, cfg
+        torch.manual_seed(99)
+        z = torch.empty(n, G, G).normal_()                          # the draw Normal.sample makes next
+        torch.manual_seed(99)
+        R = tm._infer_risk_map(num_samples=n)
+        assert torch.equal(Normal(mean_map, std_map).expand((n, G, G)).mean, mean_map.expand(n, G, G))
+        key = f"{metric}_{q}"
+        out["z"] = z.numpy()
+        out[f"R_{key}"] = R.numpy()
+    path = os.path.join(HERE, "riskmap.npz")
+    np.savez_compressed(path, **out)
+    print(f"riskmap        G={G} n={n} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     pi = math.pi
+    run_riskmap_case()
     # config 1 of BASELINE.json: test_mppi.py object graph, synthetic 64x64 map, int64 goal (test_mppi.py:132-133)
     run_case("c1_basic", G=64, res=0.5, K=128, T=20, risk_mean=smooth_risk_map(64, 0),
              start=[8.0, 8.0, pi / 4], goal=torch.tensor([24, 24]), n_solves=3, advance="follow")
