@@ -259,6 +259,21 @@ def main():
                                            "unit": "GB/s", "frac": bytes_b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "traffic": traffic_b, "kernel_ms": rb, "finish_kernel_ms": fb,
                                            "algorithmic_bytes_per_launch": bytes_b}}
+        # ---- closed loop on the device: solve -> PlanetaryEnv.step -> solve ..., one launch per control step ----
+        if world == 1:
+            plc = make_planner(inst, local)
+            plc.env_attach(inst.risk.numpy(), np.full((G, G), 0.05, np.float32))      # latent slip ~ N(risk, 0.05)
+            plc.episode(min(a.warmup, 200), inst.start.numpy())
+            t0 = time.perf_counter()
+            states, rewards, done = plc.episode(a.steps, inst.start.numpy())
+            elc = time.perf_counter() - t0
+            plc.close()
+            out["closed_loop"] = {"value": a.steps / elc, "unit": "control steps/s", "us_per_step": elc / a.steps * 1e6,
+                                  "instances": 1, "steps": a.steps,
+                                  "distance_to_goal_m": [float(np.linalg.norm(states[0, 0, :2] - inst.goal.numpy())),
+                                                         float(np.linalg.norm(states[-1, 0, :2] - inst.goal.numpy()))],
+                                  "note": "bn_mppi_episode_async: state advanced on the device by the observation-mode "
+                                          "transit with sampled slip (planetary_env.py:189-219); includes the final log copy"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds)
     if dist is not None:

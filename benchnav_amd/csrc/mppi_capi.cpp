@@ -67,6 +67,15 @@ struct bn_mppi {
     float *d_cost[2] = {nullptr, nullptr}, *d_part[2] = {nullptr, nullptr}, *d_state_copy[2] = {nullptr, nullptr};
     float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
     int *d_idx = nullptr;
+    // device-side closed loop (bn_mppi_env_attach / bn_mppi_episode_async)
+    float *d_lat_mean = nullptr, *d_lat_std = nullptr, *d_ep_states = nullptr, *d_ep_reward = nullptr, *d_env_state = nullptr;
+    float *d_ep_action = nullptr;
+    int *d_ep_done = nullptr;
+    bool env_attached = false;
+    int ep_steps = 0;            // capacity of the episode log
+    int ep_len = 0;              // steps enqueued in the current episode
+    const float *ep_z = nullptr; // (n_steps, B) device slip draws of the current episode, or nullptr
+    bool in_episode = false;
     size_t scratch_bytes = 0, eps_bytes = 0, idx_count = 0;
     float *h_pinned = nullptr;   // pinned staging for (B,3) states
     // profiling
@@ -114,6 +123,11 @@ int flush_tail(bn_mppi *h)
     bn::SolveParams p = h->p;
     const int cur = (int)((h->solves - 1) & 1);
     p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
+    if (h->in_episode) {
+        p.env_on = 1;
+        p.ep_index = h->ep_len - 1;
+        p.env_z = h->ep_z ? h->ep_z + (size_t)(h->ep_len - 1) * p.B : nullptr;
+    }
     BN_HIP(bn::launch_finish(p, h->stream));
     h->tail_pending = false;
     return BN_OK;
@@ -282,7 +296,8 @@ void bn_mppi_destroy(bn_mppi_t *h)
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1],
                     h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
-                    h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx};
+                    h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
+                    h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -422,6 +437,14 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
         // one launch: merge + tail of the previous solve ride along with this solve's rollouts
         p.have_prev = h->tail_pending ? 1 : 0;
         p.mean_from_part = h->tail_pending ? 1 : 0;
+        if (h->in_episode) {
+            // closed loop: from the second step on, the rollout workgroups advance the state themselves
+            p.env_on = 1;
+            p.closed_loop = (h->ep_len > 0 && h->tail_pending) ? 1 : 0;
+            p.ep_index = h->ep_len - 1;                                   // the env step applied / logged by this launch
+            p.env_z = (h->ep_z && h->ep_len > 0) ? h->ep_z + (size_t)(h->ep_len - 1) * p.B : nullptr;
+            h->ep_len += 1;
+        }
         BN_HIP(bn::launch_rollout(p, mode, h->stream));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
@@ -449,6 +472,83 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
         if (int rc = bn_mppi_solve_async(h, states, states_where, e, noise)) return rc;
     }
+    return BN_OK;
+}
+
+int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *latent_std, bn_mem_kind where,
+                       float goal_threshold, float delta_t, uint64_t seed)
+{
+    if (!h || !latent_mean || !latent_std) return fail(BN_ERR_INVALID, "null argument");
+    if (!h->pipelined) return fail(BN_ERR_INVALID, "the device-side closed loop needs the pipelined mode (num_samples <= 2048)");
+    if (!(goal_threshold >= 0.0f) || !(delta_t > 0.0f)) return fail(BN_ERR_INVALID, "goal_threshold >= 0 and delta_t > 0 required");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
+    BN_HIP(hipStreamSynchronize(h->stream));
+    const size_t bytes = (size_t)h->n_maps * h->p.G * h->p.G * 4;
+    if (!h->d_lat_mean) {
+        BN_HIP(hipMalloc((void **)&h->d_lat_mean, bytes));
+        BN_HIP(hipMalloc((void **)&h->d_lat_std, bytes));
+        BN_HIP(hipMalloc((void **)&h->d_env_state, (size_t)h->p.B * 3 * 4));
+        BN_HIP(hipMalloc((void **)&h->d_ep_done, (size_t)h->p.B * sizeof(int)));
+    }
+    const hipMemcpyKind kind = where == BN_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    BN_HIP(hipMemcpy(h->d_lat_mean, latent_mean, bytes, kind));
+    BN_HIP(hipMemcpy(h->d_lat_std, latent_std, bytes, kind));
+    h->p.lat_mean = h->d_lat_mean; h->p.lat_std = h->d_lat_std; h->p.env_state = h->d_env_state; h->p.ep_done = h->d_ep_done;
+    h->p.goal_thr = goal_threshold; h->p.env_dt = delta_t; h->p.env_seed = seed;
+    h->env_attached = true;
+    return BN_OK;
+}
+
+int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, bn_mem_kind states_where, const float *eps,
+                          bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride, const float *z_device)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_episode_async");
+    if (n_steps < 1) return fail(BN_ERR_INVALID, "n_steps must be >= 1");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;            // anything pending belongs to the pre-episode state
+    const size_t B = h->p.B;
+    if (n_steps > h->ep_steps) {
+        BN_HIP(hipStreamSynchronize(h->stream));
+        if (h->d_ep_states) BN_HIP(hipFree(h->d_ep_states));
+        if (h->d_ep_reward) BN_HIP(hipFree(h->d_ep_reward));
+        if (h->d_ep_action) BN_HIP(hipFree(h->d_ep_action));
+        h->d_ep_states = h->d_ep_reward = h->d_ep_action = nullptr;
+        BN_HIP(hipMalloc((void **)&h->d_ep_states, (size_t)(n_steps + 1) * B * 3 * 4));
+        BN_HIP(hipMalloc((void **)&h->d_ep_reward, (size_t)n_steps * B * 4));
+        BN_HIP(hipMalloc((void **)&h->d_ep_action, (size_t)n_steps * B * 2 * 4));
+        h->ep_steps = n_steps;
+    }
+    h->p.ep_states = h->d_ep_states; h->p.ep_reward = h->d_ep_reward; h->p.ep_action = h->d_ep_action;
+    BN_HIP(hipMemsetAsync(h->d_ep_done, 0xff, B * sizeof(int), h->stream));        // -1: goal not reached
+    if (!states0) return fail(BN_ERR_INVALID, "states0 is null");
+    if (states_where == BN_MEM_HOST) {                 // one upload; the loop below must not touch the host again
+        BN_HIP(hipStreamSynchronize(h->stream));
+        BN_HIP(hipMemcpy(h->d_state, states0, B * 3 * 4, hipMemcpyHostToDevice));
+        states0 = h->d_state;
+        states_where = BN_MEM_DEVICE;
+    }
+    h->in_episode = true;
+    h->ep_len = 0;
+    h->ep_z = z_device;
+    int rc = bn_mppi_solve_n_async(h, n_steps, states0, states_where, eps, noise, eps_ring, eps_stride);
+    if (rc == BN_OK) rc = flush_tail(h);              // the last solve's tail and the last environment step
+    h->in_episode = false;
+    return rc;
+}
+
+int bn_mppi_episode_log(bn_mppi_t *h, float *states_host, float *rewards_host, float *actions_host, int32_t *done_step_host)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!h->d_ep_states || h->ep_len < 1) return fail(BN_ERR_STATE, "no episode has been run");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(hipStreamSynchronize(h->stream));
+    const size_t B = h->p.B, n = (size_t)h->ep_len;
+    if (states_host) BN_HIP(hipMemcpy(states_host, h->d_ep_states, (n + 1) * B * 3 * 4, hipMemcpyDeviceToHost));
+    if (rewards_host) BN_HIP(hipMemcpy(rewards_host, h->d_ep_reward, n * B * 4, hipMemcpyDeviceToHost));
+    if (actions_host) BN_HIP(hipMemcpy(actions_host, h->d_ep_action, n * B * 2 * 4, hipMemcpyDeviceToHost));
+    if (done_step_host) BN_HIP(hipMemcpy(done_step_host, h->d_ep_done, B * sizeof(int), hipMemcpyDeviceToHost));
     return BN_OK;
 }
 

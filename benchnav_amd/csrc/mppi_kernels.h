@@ -46,6 +46,21 @@ struct SolveParams {
     float *state_copy;   // (B, 3)      the state this solve started from, kept for its tail
     const float *cost_prev, *part_prev, *state_prev;   // the previous solve's buffers (pipelined mode)
     float *cost_out;     // (B, K)      stable copy of the latest finished solve's costs (BN_BUF_COSTS)
+    // ---- device-side closed loop ("next" row N2): PlanetaryEnv.step between consecutive solves ----
+    int closed_loop;     // rollout workgroups derive this solve's state from the previous one + env step
+    int env_on;          // the tail logs the environment step that follows its solve
+    int ep_index;        // episode index of the solve whose tail this launch writes = index of the env step the
+                         // rollout workgroups apply in closed-loop mode (the step after that solve)
+    float goal_thr;      // PlanetaryEnv goal_threshold (planetary_env.py:215-217)
+    float env_dt;        // PlanetaryEnv delta_t passed to transit (planetary_env.py:203-205)
+    uint64_t env_seed;
+    const float *lat_mean, *lat_std;   // (n_maps, G, G) latent slip model, observation mode (traversability_model.py:65-69)
+    const float *env_z;                // (B,) slip draws of env step `ep_index`, or nullptr (Philox keyed by env_seed)
+    float *ep_states;    // (n_steps+1, B, 3) episode log
+    float *ep_reward;    // (n_steps, B)      traversability observed by each env step
+    float *ep_action;    // (n_steps, B, 2)   the control applied by each env step: U*[0] of that step's solve
+    int *ep_done;        // (B)               first step index whose resulting state is within goal_thr, or -1
+    float *env_state;    // (B, 3)            latest environment state (after the latest logged step)
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)

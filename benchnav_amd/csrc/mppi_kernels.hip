@@ -154,6 +154,49 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     c.trav = LDSWIN ? trav_window<GEO>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
 }
 
+// One PlanetaryEnv.step (planetary_env.py:189-219) for instance b: observation-mode transit with the
+// latent slip sampled at the current cell (traversability_model.py:65-69: Normal(mean, std)[cell].sample()
+// = z * std + mean), then the goal test.  An instance already within goal_thr of its goal is frozen.
+// Every workgroup that needs the next state evaluates this itself: same inputs, same operations.
+struct EnvStep { float x, y, th, reward; bool reached, frozen; };
+
+template <int GEO>
+__device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, float sx, float sy, float sth, float u0, float u1,
+                                               const float *z_ptr, uint64_t step)
+{
+    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
+    EnvStep r;
+    const float d0x = sx - gx, d0y = sy - gy;
+    r.frozen = sqrtf(d0x * d0x + d0y * d0y) < p.goal_thr;          // terminated at an earlier step
+    const int ix = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    const int iy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
+    const size_t cell = (size_t)b * p.map_stride + (size_t)iy * p.G + ix;
+    float z;
+    if (z_ptr) {
+        z = z_ptr[b];
+    } else {
+        const u32x4 q = philox4x32_10(u32x4{(uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x454e5631u},
+                                      (uint32_t)p.env_seed, (uint32_t)(p.env_seed >> 32));
+        float z1;
+        box_muller(q.x, q.y, z, z1);
+    }
+    const float slip = z * p.lat_std[cell] + p.lat_mean[cell];
+    const float trav = 1.0f - clampf(slip, 0.0f, 1.0f);
+    const float v = clampf(u0, p.umin0, p.umax0), om = clampf(u1, p.umin1, p.umax1);   // robot_model.py:82-83
+    float sn, cs;
+    sincos_spec(sth, sn, cs);
+    const float xn = sx + ((trav * v) * cs) * p.env_dt;
+    const float yn = sy + ((trav * v) * sn) * p.env_dt;
+    const float tn = sth + (trav * om) * p.env_dt;
+    r.x = r.frozen ? sx : clampf(xn, p.x0, p.x_hi);
+    r.y = r.frozen ? sy : clampf(yn, p.y0, p.y_hi);
+    r.th = r.frozen ? sth : wrap_angle(tn);
+    r.reward = trav;
+    const float dx = r.x - gx, dy = r.y - gy;
+    r.reached = sqrtf(dx * dx + dy * dy) < p.goal_thr;             // planetary_env.py:215-217
+    return r;
+}
+
 // Wave-wide butterfly reductions (ds_bpermute).  A DPP row-scan formulation was measured 0.25 us faster
 // per launch but hipcc's DPP combiner mis-folds the update_dpp + add pairs inside this kernel (wrong sums
 // on hardware, correct in an isolated test kernel), so the shuffle form stays.
@@ -292,6 +335,22 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         p.stats[b * 2 + 0] = m;
         p.stats[b * 2 + 1] = S;
     }
+    if (p.env_on && tid == 64) {
+        // the environment step that follows this solve: apply U*[0], log state, reward and goal arrival
+        const EnvStep e = env_advance<GEO>(p, b, sx, sy, sth, us[0], us[1], p.env_z, (uint64_t)p.ep_index);
+        const size_t B = p.B;
+        float *row = p.ep_states + ((size_t)(p.ep_index + 1) * B + b) * 3;
+        row[0] = e.x; row[1] = e.y; row[2] = e.th;
+        p.env_state[b * 3 + 0] = e.x; p.env_state[b * 3 + 1] = e.y; p.env_state[b * 3 + 2] = e.th;
+        p.ep_reward[(size_t)p.ep_index * B + b] = e.reward;
+        p.ep_action[((size_t)p.ep_index * B + b) * 2 + 0] = us[0];
+        p.ep_action[((size_t)p.ep_index * B + b) * 2 + 1] = us[1];
+        if (p.ep_index == 0) {
+            float *row0 = p.ep_states + (size_t)b * 3;
+            row0[0] = sx; row0[1] = sy; row0[2] = sth;
+        }
+        if (e.reached && !e.frozen && p.ep_done[b] < 0) p.ep_done[b] = p.ep_index;
+    }
     BN_STAMP(10);
 
     if (tid == 0) {
@@ -419,7 +478,9 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
 
     const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
     const float *__restrict__ eps = p.eps;
-    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    // open loop: the caller's state; closed loop: the previous solve's state, advanced below
+    const float *st_src = p.closed_loop ? p.state_prev : p.state;
+    float sx = st_src[b * 3 + 0], sy = st_src[b * 3 + 1], sth = st_src[b * 3 + 2];
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
     const uint64_t solve = p.solve;
     BN_STAMP(0);
@@ -433,7 +494,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     if (pre_ok) pre = merge_issue(part_prev, p.nblk, T, tid);
 
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
-    if (LDSWIN) {
+    if (LDSWIN && !p.closed_loop) {
         w = window_origin<GEO>(p, sx, sy);
         stage_window(win, map, w, p.WN, p.G, tid, kRolloutThreads);
     }
@@ -448,7 +509,19 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
             mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);      // mean[t] @ inv_cov (diagonal), mppi.py:179-180
         }
     }
-    if (blockIdx.x == 0 && tid < 3) p.state_copy[b * 3 + tid] = p.state[b * 3 + tid];   // for this solve's tail
+    if (p.closed_loop) {
+        // PlanetaryEnv.step with the previous solve's first control (ml[0..1] = U*_prev[0], published by the
+        // barrier inside merge_partials): every workgroup advances the state itself, no launch in between
+        const EnvStep e = env_advance<GEO>(p, b, sx, sy, sth, ml[0], ml[1], p.env_z, (uint64_t)p.ep_index);
+        sx = e.x; sy = e.y; sth = e.th;
+        if (LDSWIN) {
+            w = window_origin<GEO>(p, sx, sy);
+            stage_window(win, map, w, p.WN, p.G, tid, kRolloutThreads);
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {                 // the state this solve starts from, for its tail and the next solve
+        p.state_copy[b * 3 + 0] = sx; p.state_copy[b * 3 + 1] = sy; p.state_copy[b * 3 + 2] = sth;
+    }
     BN_BAR();
 
     // Rows of X and U are pitched to Kp = 64 * nblk floats, so every lane stores unconditionally

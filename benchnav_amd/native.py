@@ -61,6 +61,8 @@ class NativeMPPI:
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
         self.store_controls = store_controls
+        self._shared_map = shared_map or num_instances == 1
+        self._ep_steps = 0
         _capi.check(self._lib.bn_mppi_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):
@@ -125,6 +127,41 @@ class NativeMPPI:
         """Enqueue n dependent (warm-started) solves from one C call: no per-launch Python overhead."""
         _capi.check(self._lib.bn_mppi_solve_n_async(self._h, n, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
                                                     C.c_void_p(eps_ptr), kind, eps_ring, eps_stride))
+
+    # -- device-side closed loop (PlanetaryEnv.step between solves) ------------------------------
+    def env_attach(self, latent_mean, latent_std, goal_threshold: float = 1.0, delta_t: float = 0.1, seed: int = 0):
+        """Latent slip model Normal(mean, std) per cell ((G,G) shared or (n_maps,G,G)), PlanetaryEnv defaults
+        (planetary_env.py:36: goal_threshold=1.0)."""
+        n_maps = 1 if self._shared_map else self.B
+        m = _f32(latent_mean).reshape(-1, self.G, self.G)
+        s = _f32(latent_std).reshape(-1, self.G, self.G)
+        if m.shape[0] == 1 and n_maps > 1:
+            m = np.ascontiguousarray(np.repeat(m, n_maps, axis=0)); s = np.ascontiguousarray(np.repeat(s, n_maps, axis=0))
+        assert m.shape == (n_maps, self.G, self.G) and s.shape == m.shape
+        _capi.check(self._lib.bn_mppi_env_attach(self._h, C.c_void_p(m.ctypes.data), C.c_void_p(s.ctypes.data),
+                                                 _capi.BN_MEM_HOST, goal_threshold, delta_t, seed))
+
+    def episode(self, n_steps: int, states0, z_device_ptr: Optional[int] = None, eps_ptr: Optional[int] = None,
+                kind: int = _capi.BN_NOISE_PHILOX, eps_ring: int = 1, eps_stride: int = 0, wait: bool = True):
+        """n_steps closed-loop control steps on the device.  Returns (states (n+1,B,3), rewards (n,B),
+        done_step (B)) when wait=True (the applied controls (n,B,2) are kept in `last_actions`); otherwise
+        only enqueues (read the log later with episode_log())."""
+        st = _f32(states0).reshape(self.B, 3)
+        _capi.check(self._lib.bn_mppi_episode_async(self._h, n_steps, C.c_void_p(st.ctypes.data), _capi.BN_MEM_HOST,
+                                                    C.c_void_p(eps_ptr), kind, eps_ring, eps_stride, C.c_void_p(z_device_ptr)))
+        self._ep_steps = n_steps
+        return self.episode_log() if wait else None
+
+    def episode_log(self):
+        n = self._ep_steps
+        states = np.empty((n + 1, self.B, 3), np.float32)
+        rewards = np.empty((n, self.B), np.float32)
+        actions = np.empty((n, self.B, 2), np.float32)
+        done = np.empty(self.B, np.int32)
+        _capi.check(self._lib.bn_mppi_episode_log(self._h, _fp(states), _fp(rewards), _fp(actions),
+                                                  done.ctypes.data_as(C.POINTER(C.c_int32))))
+        self.last_actions = actions
+        return states, rewards, done
 
     def sync(self):
         """Write the pending tail of the latest solve and wait for the stream."""

@@ -153,6 +153,28 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
  * other work on the same stream).  Noise block i is eps + (i % eps_ring) * eps_stride floats. */
 int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
+/*
+ * Device-side closed loop: PlanetaryEnv.step (planetary_env.py:189-219) between consecutive solves, for
+ * all B instances, without a host round trip per control step (the reference loop: test_mppi.py:171-198).
+ *   env_attach   latent slip model Normal(mean, std) per cell, (n_maps,G,G) each (grid_map.distributions
+ *                ["latent_models"], sampled in observation mode: traversability_model.py:65-69),
+ *                goal_threshold (planetary_env.py:215-217), the environment's delta_t, Philox key.
+ *   episode      n_steps control steps: solve at the current state, apply U*[0] through the observation-mode
+ *                transit with a freshly sampled slip, test the goal; an instance that has reached its goal
+ *                stays frozen.  z_device: optional (n_steps, B) standard normals for the slip draws (parity
+ *                tests), NULL = in-kernel Philox.  One launch per control step (K <= 2048 only).
+ *   episode_log  states (n_steps+1, B, 3) incl. the initial one, rewards (n_steps, B) = traversability
+ *                observed by each step (planetary_env.py:209), actions (n_steps, B, 2) = the control each step
+ *                applied (action_seq[0] of test_mppi.py:181), done_step (B) = first step whose resulting
+ *                state lies within goal_threshold, or -1.  Any pointer may be NULL.  Synchronises.
+ */
+int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *latent_std, bn_mem_kind where,
+                       float goal_threshold, float delta_t, uint64_t seed);
+int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, bn_mem_kind states_where,
+                          const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride,
+                          const float *z_device);
+int bn_mppi_episode_log(bn_mppi_t *h, float *states_host, float *rewards_host, float *actions_host,
+                        int32_t *done_step_host);
 int bn_mppi_sync(bn_mppi_t *h);
 /* Enqueue the pending tail (if any) without waiting. */
 int bn_mppi_flush(bn_mppi_t *h);
