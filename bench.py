@@ -151,12 +151,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MPPI planner has no CPU fallback")
+    local = local % torch.cuda.device_count()      # identity on a full node; lets a 1-GPU box rehearse the N > 1 path
     torch.cuda.set_device(local)
     dist = None
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     def sync():
         if dist is not None:
@@ -181,7 +186,8 @@ def main():
     pl = settle(lambda: make_planner(inst, local), state_dev, eps_ring, kind, a.warmup, torch.cuda.synchronize)
     elapsed = timed_solves(pl, state_dev, eps_ring, kind, a.steps, sync)
     from benchnav_amd.sharding import gather_throughput
-    job = gather_throughput(a.steps, elapsed, device=torch.device("cuda", local) if dist is not None else None)
+    job = gather_throughput(a.steps, elapsed,
+                            device=torch.device("cuda", local) if (dist is not None and backend == "nccl") else None)
     elapsed = job["max_seconds"]                                   # the only collective: 16 bytes per rank
     value = job["total_solves"] / elapsed
     alg_bytes = pl.algorithmic_bytes(injected_noise=(a.noise == "injected"))
