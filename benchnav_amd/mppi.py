@@ -160,13 +160,13 @@ class MPPI(nn.Module):
         return torch.as_tensor(_DevArray(ptr.value, shape), device=self._device)
 
     def __del__(self):
-        h = getattr(self, "_handle", None)
-        if h is not None and h.value:
-            try:
+        try:                                   # also runs during interpreter shutdown, when module globals are gone
+            h = self.__dict__.get("_handle")
+            if h is not None and h.value:
                 self._lib.bn_mppi_destroy(h)
-            except Exception:
-                pass
-            self._handle = C.c_void_p()
+                h.value = None
+        except Exception:
+            pass
 
     def set_risk_map(self, risks: torch.Tensor) -> None:
         """Replace the risk map (dynamics._traversability_model._risks, (G,G) [iy,ix])."""
