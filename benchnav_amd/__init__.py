@@ -7,7 +7,10 @@ from .native import NativeMPPI  # noqa: F401
 
 
 def __getattr__(name):
-    if name == "MPPI":          # torch is imported only when the torch-facing class is used
+    if name == "MPPI":          # torch is imported only when the torch-facing classes are used
         from .mppi import MPPI
         return MPPI
+    if name == "DWA":
+        from .dwa import DWA
+        return DWA
     raise AttributeError(name)

@@ -552,6 +552,45 @@ int bn_mppi_episode_log(bn_mppi_t *h, float *states_host, float *rewards_host, f
     return BN_OK;
 }
 
+int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actions_host, int32_t num_actions,
+                      const float *stage_goal_host, float *best_action_host, float *best_states_host,
+                      float *costs_host, float *weights_host, float *states_all_host, int32_t *best_index_host)
+{
+    if (!h || !states_host || !actions_host) return fail(BN_ERR_INVALID, "null argument");
+    if (num_actions < 1 || num_actions > 1024) return fail(BN_ERR_INVALID, "num_actions must be in [1, 1024]");
+    if (!h->map_set || !h->goal_set) return fail(BN_ERR_STATE, "set_map and set_goal must precede dwa_solve");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
+    const size_t B = h->p.B, NA = num_actions, T1 = h->p.T + 1;
+    // scratch layout: actions | stage goal | X | cost | w | best
+    const size_t n_act = B * NA * 2, n_goal = B * 2, n_X = B * NA * T1 * 3, n_c = B * NA;
+    const size_t floats = n_act + n_goal + n_X + 2 * n_c + B;
+    if (int rc = ensure_scratch(h, floats * 4)) return rc;
+    float *d_act = h->d_scratch, *d_goal = d_act + n_act, *d_X = d_goal + n_goal, *d_c = d_X + n_X, *d_w = d_c + n_c;
+    int *d_best = reinterpret_cast<int *>(d_w + n_c);
+    BN_HIP(hipStreamSynchronize(h->stream));
+    BN_HIP(hipMemcpy(h->d_state, states_host, B * 3 * 4, hipMemcpyHostToDevice));
+    BN_HIP(hipMemcpy(d_act, actions_host, n_act * 4, hipMemcpyHostToDevice));
+    if (stage_goal_host) BN_HIP(hipMemcpy(d_goal, stage_goal_host, n_goal * 4, hipMemcpyHostToDevice));
+    else BN_HIP(hipMemcpy(d_goal, h->d_goal, n_goal * 4, hipMemcpyDeviceToDevice));          // no reference path: the goal (dwa.py:243-247)
+    bn::SolveParams p = h->p;
+    p.state = h->d_state;
+    BN_HIP(bn::launch_dwa(p, d_act, d_goal, num_actions, d_X, d_c, d_w, d_best, h->stream));
+    std::vector<int> best(B);
+    BN_HIP(hipMemcpyAsync(best.data(), d_best, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (costs_host) BN_HIP(hipMemcpyAsync(costs_host, d_c, n_c * 4, hipMemcpyDeviceToHost, h->stream));
+    if (weights_host) BN_HIP(hipMemcpyAsync(weights_host, d_w, n_c * 4, hipMemcpyDeviceToHost, h->stream));
+    if (states_all_host) BN_HIP(hipMemcpyAsync(states_all_host, d_X, n_X * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    for (size_t b = 0; b < B; ++b) {
+        if (best_index_host) best_index_host[b] = best[b];
+        if (best_action_host) std::memcpy(best_action_host + b * 2, actions_host + (b * NA + best[b]) * 2, 8);
+        if (best_states_host)
+            BN_HIP(hipMemcpy(best_states_host + b * T1 * 3, d_X + (b * NA + best[b]) * T1 * 3, T1 * 3 * 4, hipMemcpyDeviceToHost));
+    }
+    return BN_OK;
+}
+
 int bn_mppi_sync(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");

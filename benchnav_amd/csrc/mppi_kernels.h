@@ -73,6 +73,8 @@ size_t finish_lds_bytes(const SolveParams &p);
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
+hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
+                      float *w, int *best, hipStream_t s);
 
 // layout conversion helpers (planner-native k-fastest <-> reference k-major)
 hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s);   // (T1,3,Kp)->(K,T1,3)

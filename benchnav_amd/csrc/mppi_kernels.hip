@@ -713,6 +713,85 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParam
     finish_body<GEO, LDSWIN>(p, blockIdx.x, p.part, p.cost, p.state, smem);
 }
 
+// ------------------------------------------------------------------------------
+// DWA ("next" row N3): reference src/planners/local_planners/dwa.py:116-258.  NA constant-control candidates
+// (the dynamic window grid, built by the host exactly as dwa.py:168-199 does) are rolled out with the same
+// transit / aliasing as MPPI (dwa.py:224-227), costed with the stage cost against the sub-goal and the
+// terminal cost against the goal, accumulated in fp32 in step order like `cost_batch +=` (dwa.py:251-256);
+// argmin (first minimum, dwa.py:139), weights = softmax(-cost) (dwa.py:151).
+// grid = B, block = 64 * ceil(NA / 64) <= 1024, lane = candidate.  LDS: [ window | red 2*16 ].
+// ------------------------------------------------------------------------------
+template <int GEO, bool LDSWIN>
+__global__ void dwa_kernel(const SolveParams p, const float *__restrict__ actions, const float *__restrict__ stage_goal,
+                           int NA, float *__restrict__ Xall, float *__restrict__ cost_out, float *__restrict__ w_out,
+                           int *__restrict__ best_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.T;
+    float *win = smem;
+    float *red = win + (LDSWIN ? p.WN * p.WN : 0);
+    int *redi = reinterpret_cast<int *>(red + 16);
+    const int tid = threadIdx.x, b = blockIdx.x, nthreads = blockDim.x;
+    const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
+    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];                 // terminal cost: the goal
+    const float hx = stage_goal[b * 2 + 0], hy = stage_goal[b * 2 + 1];         // stage cost: the sub-goal
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (LDSWIN) {
+        w = window_origin<GEO>(p, sx, sy);
+        stage_window(win, map, w, p.WN, p.G, tid, nthreads);
+    }
+    __syncthreads();
+    const bool active = tid < NA;
+    const int k = active ? tid : NA - 1;
+    const float u0 = clampf(actions[((size_t)b * NA + k) * 2 + 0], p.umin0, p.umax0);   // transit re-clamps (robot_model.py:82-83)
+    const float u1 = clampf(actions[((size_t)b * NA + k) * 2 + 1], p.umin1, p.umax1);
+    Chain c;
+    c.x = sx; c.y = sy; c.th = sth;
+    sincos_spec(c.th, c.sn, c.cs);
+    c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
+    float *Xk = Xall ? Xall + ((size_t)b * NA + k) * (T + 1) * 3 : nullptr;
+    float cost = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        float xn, yn, tn;
+        if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+        else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, u0, u1, xn, yn, tn);
+        if (Xk && active) { Xk[3 * t] = xn; Xk[3 * t + 1] = yn; Xk[3 * t + 2] = tn; }
+        const float dx = xn - hx, dy = yn - hy;
+        cost = cost + (sqrtf(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));      // objectives.py:47-53
+    }
+    if (Xk && active) { Xk[3 * T] = c.x; Xk[3 * T + 1] = c.y; Xk[3 * T + 2] = c.th; }
+    const float dxT = c.x - gx, dyT = c.y - gy;
+    cost = cost + (sqrtf(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f));       // dwa.py:256
+    if (active) cost_out[(size_t)b * NA + tid] = cost;
+
+    // argmin with first-index tie break, then softmax(-cost)
+    float cm = active ? cost : INFINITY;
+    int im = active ? tid : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float oc = __shfl_xor(cm, o);
+        const int oi = __shfl_xor(im, o);
+        if (oc < cm || (oc == cm && oi < im)) { cm = oc; im = oi; }
+    }
+    const int wv = tid >> 6, nw = nthreads >> 6;
+    if ((tid & 63) == 0) { red[wv] = cm; redi[wv] = im; }
+    __syncthreads();
+    float cmin = red[0];
+    int imin = redi[0];
+    for (int i = 1; i < nw; ++i)
+        if (red[i] < cmin || (red[i] == cmin && redi[i] < imin)) { cmin = red[i]; imin = redi[i]; }
+    __syncthreads();
+    const float e = active ? expf((-cost) - (-cmin)) : 0.0f;
+    float es = wave_sum(e);
+    if ((tid & 63) == 0) red[wv] = es;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int i = 0; i < nw; ++i) tot += red[i];
+    if (active) w_out[(size_t)b * NA + tid] = e / tot;
+    if (tid == 0) best_out[b] = imin;
+}
+
 // ---- layout helpers -----------------------------------------------------------
 __global__ void soa_to_aos_kernel(const float *__restrict__ in, float *__restrict__ out, int K, int Kp, int R)
 {   // in (R, Kp pitch) -> out (K, R)
@@ -835,6 +914,27 @@ hipError_t launch_finish(const SolveParams &p, hipStream_t s)
 }
 
 static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256); }
+
+hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
+                      float *w, int *best, hipStream_t s)
+{
+    const int threads = ((NA + 63) / 64) * 64;
+    const size_t lds = sizeof(float) * ((size_t)p.WN * p.WN + 32);
+    const bool win = p.WN > 0;
+#define BN_DWA_LAUNCH(GEO_)                                                                                          \
+    do {                                                                                                             \
+        if (win) { hipError_t e = ensure_lds(dwa_kernel<GEO_, true>, lds); if (e != hipSuccess) return e;           \
+                   dwa_kernel<GEO_, true><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best); } \
+        else { dwa_kernel<GEO_, false><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best); }   \
+    } while (0)
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: BN_DWA_LAUNCH(kGeoPow2Origin0); break;
+    case kGeoPow2: BN_DWA_LAUNCH(kGeoPow2); break;
+    default: BN_DWA_LAUNCH(kGeoGeneral); break;
+    }
+#undef BN_DWA_LAUNCH
+    return hipGetLastError();
+}
 
 hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s)
 {

@@ -128,6 +128,26 @@ class NativeMPPI:
         _capi.check(self._lib.bn_mppi_solve_n_async(self._h, n, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
                                                     C.c_void_p(eps_ptr), kind, eps_ring, eps_stride))
 
+    # -- DWA on the same transit / cost kernels -------------------------------------------------
+    def dwa_solve(self, states, actions, stage_goal=None):
+        """Roll out and cost constant-control candidates `actions` (B,NA,2) or (NA,2); see bn_mppi_dwa_solve.
+        Returns dict(best_action (B,2), best_states (B,T+1,3), costs, weights (B,NA), states (B,NA,T+1,3), best_index (B))."""
+        st = _f32(states).reshape(self.B, 3)
+        act = _f32(actions)
+        if act.ndim == 2:
+            act = np.ascontiguousarray(np.broadcast_to(act, (self.B,) + act.shape))
+        NA = act.shape[1]
+        assert act.shape == (self.B, NA, 2)
+        sg = None if stage_goal is None else _f32(stage_goal).reshape(self.B, 2)
+        out = dict(best_action=np.empty((self.B, 2), np.float32), best_states=np.empty((self.B, self.T + 1, 3), np.float32),
+                   costs=np.empty((self.B, NA), np.float32), weights=np.empty((self.B, NA), np.float32),
+                   states=np.empty((self.B, NA, self.T + 1, 3), np.float32), best_index=np.empty(self.B, np.int32))
+        _capi.check(self._lib.bn_mppi_dwa_solve(self._h, _fp(st), _fp(act), NA, None if sg is None else _fp(sg),
+                                                _fp(out["best_action"]), _fp(out["best_states"]), _fp(out["costs"]),
+                                                _fp(out["weights"]), _fp(out["states"]),
+                                                out["best_index"].ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
     # -- device-side closed loop (PlanetaryEnv.step between solves) ------------------------------
     def env_attach(self, latent_mean, latent_std, goal_threshold: float = 1.0, delta_t: float = 0.1, seed: int = 0):
         """Latent slip model Normal(mean, std) per cell ((G,G) shared or (n_maps,G,G)), PlanetaryEnv defaults

@@ -175,6 +175,19 @@ int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, b
                           const float *z_device);
 int bn_mppi_episode_log(bn_mppi_t *h, float *states_host, float *rewards_host, float *actions_host,
                         int32_t *done_step_host);
+/*
+ * DWA.forward(state), reference src/planners/local_planners/dwa.py:116-153, on the planner handle's map, goal and
+ * geometry.  The caller supplies the dynamic-window candidates (dwa.py:168-199: cartesian_prod of two linspaces),
+ * (B, num_actions, 2) constant (v, omega) pairs; each is rolled out `horizon` steps with the MPPI transit/aliasing
+ * (dwa.py:224-227), costed against `stage_goal` (the sub-goal of dwa.py:260-285, NULL = the goal) per stage and
+ * against the goal at the end, summed in fp32 in step order (dwa.py:251-256).
+ *   best_action (B,2), best_states (B,T+1,3): the argmin candidate (first minimum)        dwa.py:139-143
+ *   costs, weights (B,num_actions): cost_batch and softmax(-cost_batch)                    dwa.py:151
+ *   states_all (B,num_actions,T+1,3): _state_seq_batch; best_index (B).  Any output may be NULL.  Synchronous.
+ */
+int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actions_host, int32_t num_actions,
+                      const float *stage_goal_host, float *best_action_host, float *best_states_host,
+                      float *costs_host, float *weights_host, float *states_all_host, int32_t *best_index_host);
 int bn_mppi_sync(bn_mppi_t *h);
 /* Enqueue the pending tail (if any) without waiting. */
 int bn_mppi_flush(bn_mppi_t *h);

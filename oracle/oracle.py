@@ -118,3 +118,14 @@ def sincos(x, trig=TRIG_SPEC):
     s = np.empty_like(x); c = np.empty_like(x)
     lib().oracle_sincos(C.c_int32(trig), C.c_int64(x.size), _fp(x), _fp(s), _fp(c))
     return s, c
+
+
+def dwa(p: OracleParams, R, state, actions, sub_goal=None):
+    """DWA.forward for constant-control candidates `actions` (NA,2). Returns dict(X, cost, w, best)."""
+    R = _f32(R, (p.G, p.G)); state = _f32(state, (3,)); actions = _f32(actions)
+    NA = actions.shape[0]
+    sg = _f32(sub_goal if sub_goal is not None else [p.goal[0], p.goal[1]], (2,))
+    X = np.empty((NA, p.T + 1, 3), np.float32); cost = np.empty(NA, np.float32); w = np.empty(NA, np.float32)
+    lib().oracle_dwa.restype = C.c_int32
+    best = lib().oracle_dwa(C.byref(p), _fp(R), _fp(state), _fp(actions), C.c_int32(NA), _fp(sg), _fp(X), _fp(cost), _fp(w))
+    return dict(X=X, cost=cost, w=w, best=int(best))

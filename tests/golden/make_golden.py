@@ -150,9 +150,42 @@ def run_riskmap_case():
     print(f"riskmap        G={G} n={n} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_dwa_case():
+    """DWA (dwa.py:116-258): three consecutive forwards (dynamic window follows the previous action) with a
+    reference path, on the c1_stuck map."""
+    from src.planners.local_planners.dwa import DWA
+    G, res, T = 64, 0.5, 20
+    goal = torch.tensor([24.0, 24.0])
+    gm, dyn, obj = build_reference(G, res, iid_risk_map(G, 1) * 0.6, torch.full((G, G), 0.1), "expected_value", None, goal, 0.3)
+    solver = DWA(horizon=T, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, a_lim=torch.tensor([0.5, 1.0]),
+                 delta_t=0.1, lookahead_distance=1.0, num_lin_vel=10, num_ang_vel=10, device=torch.device("cpu"))
+    path = torch.stack([torch.linspace(8, 24, 30), torch.linspace(8, 24, 30) + 2 * torch.sin(torch.linspace(0, 3.14, 30))], dim=1)
+    solver.update_reference_path(path)
+    out = dict(R=dyn._traversability_model._risks.numpy(), G=G, res=res, T=T, thr=0.3, goal=goal.numpy(), path=path.numpy(),
+               a_lim=np.array([0.5, 1.0], np.float32), delta_t=0.1, lookahead=1.0, nv=10, nw=10, n_solves=3,
+               torch_version=torch.__version__)
+    state = torch.tensor([8.0, 8.0, 0.3])
+    for i in range(3):
+        actions = solver._generate_actions()
+        sub_goal = solver._select_sub_goal(state)
+        with torch.no_grad():
+            a_opt, x_opt = solver(state.clone())
+        cost = solver._compute_costs(solver._state_seq_batch, actions)
+        out[f"state_{i}"] = state.numpy().copy(); out[f"actions_{i}"] = actions.numpy().copy()
+        out[f"sub_goal_{i}"] = sub_goal.numpy().copy(); out[f"a_opt_{i}"] = a_opt.numpy().copy()
+        out[f"x_opt_{i}"] = x_opt[0].numpy().copy(); out[f"cost_{i}"] = cost.numpy().copy()
+        out[f"w_{i}"] = solver._weights.numpy().copy(); out[f"X_{i}"] = solver._state_seq_batch.numpy().copy()
+        state = x_opt[0, 3].clone()
+        state[2] = (state[2] + math.pi) % (2 * math.pi) - math.pi
+    p_ = os.path.join(HERE, "dwa.npz")
+    np.savez_compressed(p_, **out)
+    print(f"dwa            G={G} T={T} candidates=100 solves=3 -> {os.path.getsize(p_)/1024:.0f} KiB")
+
+
 def main():
     pi = math.pi
     run_riskmap_case()
+    run_dwa_case()
     # config 1 of BASELINE.json: test_mppi.py object graph, synthetic 64x64 map, int64 goal (test_mppi.py:132-133)
     run_case("c1_basic", G=64, res=0.5, K=128, T=20, risk_mean=smooth_risk_map(64, 0),
              start=[8.0, 8.0, pi / 4], goal=torch.tensor([24, 24]), n_solves=3, advance="follow")

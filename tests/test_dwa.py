@@ -1,0 +1,85 @@
+"""DWA on the MPPI transit/cost kernels ("next" row N3): reference src/planners/local_planners/dwa.py.
+CPU: the C oracle against the fixture captured from the reference.  GPU: kernel vs oracle (bit-exact
+trajectories and costs) and vs the fixture; the drop-in class end to end."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN_DIR
+from oracle import oracle as O
+
+
+def _fx():
+    z = np.load(os.path.join(GOLDEN_DIR, "dwa.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _params(fx):
+    return O.make_params(100, int(fx["T"]), int(fx["G"]), float(fx["res"]), fx["goal"], thr=float(fx["thr"]), trig=O.TRIG_SPEC)
+
+
+def test_oracle_dwa_matches_reference_fixture():
+    fx = _fx()
+    p = _params(fx)
+    for i in range(int(fx["n_solves"])):
+        got = O.dwa(p, fx["R"], fx[f"state_{i}"], fx[f"actions_{i}"], fx[f"sub_goal_{i}"])
+        assert np.abs(got["X"] - fx[f"X_{i}"]).max() <= 1e-4
+        c = fx[f"cost_{i}"]
+        assert (np.abs(got["cost"] - c) <= 1e-3 * np.maximum(1, np.abs(c))).all()
+        assert got["best"] == int(np.argmin(c))
+        assert np.abs(got["w"] - fx[f"w_{i}"]).max() <= 5e-3
+        assert np.abs(got["X"][got["best"]] - fx[f"x_opt_{i}"]).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_kernel_matches_oracle_and_reference():
+    from benchnav_amd import NativeMPPI
+    fx = _fx()
+    p = _params(fx)
+    with NativeMPPI(horizon=int(fx["T"]), num_samples=64, grid_size=int(fx["G"]), resolution=float(fx["res"]),
+                    stuck_threshold=float(fx["thr"])) as pl:
+        pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
+        for i in range(int(fx["n_solves"])):
+            out = pl.dwa_solve(fx[f"state_{i}"], fx[f"actions_{i}"], fx[f"sub_goal_{i}"])
+            orc = O.dwa(p, fx["R"], fx[f"state_{i}"], fx[f"actions_{i}"], fx[f"sub_goal_{i}"])
+            assert np.array_equal(out["states"][0], orc["X"]) and np.array_equal(out["costs"][0], orc["cost"])
+            assert int(out["best_index"][0]) == orc["best"] and np.abs(out["weights"][0] - orc["w"]).max() < 1e-6
+            assert np.array_equal(out["best_action"][0], fx[f"actions_{i}"][orc["best"]])
+            assert np.array_equal(out["best_states"][0], orc["X"][orc["best"]])
+            assert np.abs(out["states"][0] - fx[f"X_{i}"]).max() <= 1e-4
+            assert np.abs(out["weights"][0] - fx[f"w_{i}"]).max() <= 5e-3
+        # no reference path: stage cost against the goal (dwa.py:243-247); ragged candidate count
+        acts = fx["actions_0"][:37]
+        o2 = pl.dwa_solve(fx["state_0"], acts)
+        r2 = O.dwa(p, fx["R"], fx["state_0"], acts, None)
+        assert np.array_equal(o2["costs"][0], r2["cost"]) and int(o2["best_index"][0]) == r2["best"]
+
+
+@pytest.mark.gpu
+def test_drop_in_class_follows_the_reference_run():
+    import torch
+    from helpers import FakeDynamics, FakeGridMap, FakeObjectives
+    from benchnav_amd import DWA
+    fx = _fx()
+    gm = FakeGridMap(int(fx["G"]), float(fx["res"]))
+    dyn = FakeDynamics(fx["R"], gm)
+    obj = FakeObjectives(torch.tensor(fx["goal"]), float(fx["thr"]))
+    solver = DWA(horizon=int(fx["T"]), dim_state=3, dim_control=2, dynamics=dyn, objectives=obj,
+                 a_lim=torch.tensor(fx["a_lim"]), delta_t=float(fx["delta_t"]), lookahead_distance=float(fx["lookahead"]),
+                 num_lin_vel=int(fx["nv"]), num_ang_vel=int(fx["nw"]))
+    solver.update_reference_path(torch.tensor(fx["path"]))
+    same_build = str(fx["torch_version"]) == torch.__version__
+    for i in range(int(fx["n_solves"])):
+        state = torch.tensor(fx[f"state_{i}"])
+        if i > 0:                                        # teacher forcing: the window follows the REFERENCE's previous pick
+            solver._previous_action_seq = torch.tensor(fx[f"a_opt_{i - 1}"], device="cuda")
+        acts = solver._generate_actions()
+        assert np.abs(acts.numpy() - fx[f"actions_{i}"]).max() <= (0 if same_build else 1e-6)
+        assert np.array_equal(solver._select_sub_goal(state).numpy(), fx[f"sub_goal_{i}"])
+        a_opt, x_opt = solver(state)
+        assert a_opt.shape == (1, 2) and x_opt.shape == (1, int(fx["T"]) + 1, 3) and a_opt.is_cuda
+        assert np.abs(a_opt.cpu().numpy() - fx[f"a_opt_{i}"]).max() <= 1e-6
+        assert np.abs(x_opt[0].cpu().numpy() - fx[f"x_opt_{i}"]).max() <= 1e-4
+        top_s, top_w = solver.get_top_samples()
+        assert top_s.shape == (100, int(fx["T"]) + 1, 3) and torch.all(top_w[:-1] >= top_w[1:])
