@@ -222,7 +222,7 @@ def main():
                        "parallelism": f"instance sharding x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bn::rollout_kernel (4 role-specialised waves per 64 rollouts; in the pipelined "
+                         "kernel": "bn::rollout_kernel (5 role-specialised waves per 64 rollouts; in the pipelined "
                                    "mode it also carries the previous solve's merge + tail workgroup)",
                          "kernel_ms": r_ms, "finish_kernel_ms": f_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_prof,
@@ -280,6 +280,21 @@ def main():
                                                          float(np.linalg.norm(states[-1, 0, :2] - inst.goal.numpy()))],
                                   "note": "bn_mppi_episode_async: state advanced on the device by the observation-mode "
                                           "transit with sampled slip (planetary_env.py:189-219); includes the final log copy"}
+        # ---- BASELINE config 3: K=8192, T=50, slip sampled per lookup from Normal(mean, std) (Philox in-kernel) ----
+        if world == 1:
+            K3 = 8192
+            pl3 = NativeMPPI(horizon=T, num_samples=K3, grid_size=G, resolution=RES, device_id=local, profile=True,
+                             sampled_slip=True, stream=torch.cuda.current_stream().cuda_stream)
+            pl3.set_map(inst.risk.numpy()); pl3.set_slip_std(synth.slip_std_map(G, seed=0).numpy()); pl3.set_goal(inst.goal.numpy())
+            n3 = max(50, a.steps // 10)
+            timed_solves(pl3, state_dev, None, kind, 50, torch.cuda.synchronize)
+            pl3.kernel_ms()
+            el3 = timed_solves(pl3, state_dev, None, kind, n3, torch.cuda.synchronize)
+            r3, f3, _ = pl3.kernel_ms()
+            pl3.close()
+            out["sampled_slip"] = {"workload": f"mppi_solve K={K3} T={T} map={G}x{G}, slip ~ Normal(mean, std)[cell] drawn per lookup",
+                                   "value": n3 / el3, "unit": "solves/s", "us_per_solve": el3 / n3 * 1e6,
+                                   "draws_per_solve": K3 * (2 * T + 1) + T, "kernel_ms": r3, "finish_kernel_ms": f3}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds)
     if dist is not None:

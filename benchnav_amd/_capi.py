@@ -20,6 +20,7 @@ BN_MEM_HOST, BN_MEM_DEVICE = 0, 1
  BN_BUF_MEAN, BN_BUF_MAP, BN_BUF_GOAL) = range(9)
 BN_FLAG_STORE_CONTROLS, BN_FLAG_SHARED_MAP, BN_FLAG_NO_LDS_WINDOW, BN_FLAG_PROFILE, BN_FLAG_PRIVATE_STREAM = 1, 2, 4, 8, 16
 BN_FLAG_NO_PIPELINE = 32
+BN_FLAG_SAMPLED_SLIP = 64
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
 ABI_VERSION = 1
 
@@ -44,6 +45,8 @@ SYMBOLS = {
     "bn_mppi_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "bn_mppi_destroy": (None, [_H]),
     "bn_mppi_set_map": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int]),
+    "bn_mppi_set_slip_std": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int]),
+    "bn_mppi_set_slip_noise": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bn_mppi_set_goal": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_set_mean": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_get_mean": (C.c_int, [_H, C.c_int32, _FP]),

@@ -67,6 +67,8 @@ struct bn_mppi {
     float *d_cost[2] = {nullptr, nullptr}, *d_part[2] = {nullptr, nullptr}, *d_state_copy[2] = {nullptr, nullptr};
     float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
     int *d_idx = nullptr;
+    float *d_slip_std = nullptr;     // sampled-slip mode
+    bool slip_std_set = false;
     // device-side closed loop (bn_mppi_env_attach / bn_mppi_episode_async)
     float *d_lat_mean = nullptr, *d_lat_std = nullptr, *d_ep_states = nullptr, *d_ep_reward = nullptr, *d_env_state = nullptr;
     float *d_ep_action = nullptr;
@@ -282,7 +284,13 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.state_copy = h->d_state_copy[0]; p.cost_out = h->d_cost_out;
     p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats;
     // every rollout workgroup re-merges the previous solve's nblk partials: only worth it while they are few
-    h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 32;
+    p.slip_on = (cfg->flags & BN_FLAG_SAMPLED_SLIP) ? 1 : 0;
+    h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 32 && !p.slip_on;
+    if (p.slip_on) {
+        BN_HIP(hipMalloc((void **)&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4));
+        BN_HIP(hipMemset(h->d_slip_std, 0, (size_t)h->n_maps * p.G * p.G * 4));
+        p.slip_std = h->d_slip_std;
+    }
     BN_HIP(hipDeviceSynchronize());
     *out = h;
     return BN_OK;
@@ -297,7 +305,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1],
                     h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
                     h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
-                    h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action};
+                    h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -318,6 +326,32 @@ int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_ki
     BN_HIP(hipStreamSynchronize(h->stream));
     for (int m = lo; m < hi; ++m) BN_HIP(hipMemcpy(h->d_map + (size_t)m * h->p.G * h->p.G, risk, bytes, kind));
     h->map_set = true;
+    return BN_OK;
+}
+
+int bn_mppi_set_slip_std(bn_mppi_t *h, int32_t instance, const float *stdv, bn_mem_kind where)
+{
+    if (int rc = check_instance(h, instance, true)) return rc;
+    if (!stdv) return fail(BN_ERR_INVALID, "std is null");
+    if (!h->p.slip_on) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_SAMPLED_SLIP");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    if (int rc = flush_tail(h)) return rc;
+    BN_HIP(hipStreamSynchronize(h->stream));
+    const size_t bytes = (size_t)h->p.G * h->p.G * 4;
+    const hipMemcpyKind kind = where == BN_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const int lo = instance < 0 ? 0 : std::min(instance, h->n_maps - 1), hi = instance < 0 ? h->n_maps : lo + 1;
+    for (int m = lo; m < hi; ++m) BN_HIP(hipMemcpy(h->d_slip_std + (size_t)m * h->p.G * h->p.G, stdv, bytes, kind));
+    h->slip_std_set = true;
+    return BN_OK;
+}
+
+int bn_mppi_set_slip_noise(bn_mppi_t *h, const float *zt_device, const float *zc_device, const float *zo_device)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!h->p.slip_on) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_SAMPLED_SLIP");
+    if ((zt_device == nullptr) != (zc_device == nullptr) || (zt_device == nullptr) != (zo_device == nullptr))
+        return fail(BN_ERR_INVALID, "give all three arrays or none");
+    h->p.zt = zt_device; h->p.zc = zc_device; h->p.zo = zo_device;
     return BN_OK;
 }
 
@@ -453,6 +487,10 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     }
     p.have_prev = 0;
     p.mean_from_part = 0;
+    if (p.slip_on) {
+        if (!h->slip_std_set) return fail(BN_ERR_STATE, "bn_mppi_set_slip_std must precede solve in sampled-slip mode");
+        BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
+    } else
     BN_HIP(bn::launch_rollout(p, mode, h->stream));
     if (prof) BN_HIP(hipEventRecord(ev[1], h->stream));
     p.state = p.state_copy;

@@ -61,6 +61,10 @@ struct SolveParams {
     float *ep_action;    // (n_steps, B, 2)   the control applied by each env step: U*[0] of that step's solve
     int *ep_done;        // (B)               first step index whose resulting state is within goal_thr, or -1
     float *env_state;    // (B, 3)            latest environment state (after the latest logged step)
+    // ---- sampled slip inside the rollouts (BASELINE config 3; reference A9: traversability_model.py:65-69) ----
+    int slip_on;         // every traversability lookup draws slip ~ Normal(map, slip_std)[cell]
+    const float *slip_std;             // (n_maps, G, G)
+    const float *zt, *zc, *zo;         // injected standard normals: transit (B,T,K), cost (B,T+1,K), X* (B,T); or nullptr: Philox
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)
@@ -73,6 +77,7 @@ size_t finish_lds_bytes(const SolveParams &p);
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
                       float *w, int *best, hipStream_t s);
 

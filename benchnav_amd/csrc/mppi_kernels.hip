@@ -197,6 +197,36 @@ __device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, floa
     return r;
 }
 
+// Sampled-slip helpers (BASELINE config 3, see rollout_sampled_kernel): one standard normal per lookup, from the
+// caller's arrays or the Philox stream, and the observation-mode traversability 1 - clamp(z*std + mean, 0, 1).
+__device__ __forceinline__ float slip_normal(const SolveParams &p, const float *z, size_t idx, uint32_t b, uint32_t k,
+                                             uint32_t t, uint32_t kind)
+{
+    if (z) return z[idx];
+    const u32x4 q = philox4x32_10(u32x4{k, t, (uint32_t)p.solve ^ (b << 20), 0x534c4950u + kind}, (uint32_t)p.seed,
+                                  (uint32_t)(p.seed >> 32));
+    float z0, z1;
+    box_muller(q.x, q.y, z0, z1);
+    return z0;
+}
+
+template <int GEO, bool LDSWIN>
+__device__ __forceinline__ float trav_sampled(const SolveParams &p, const float *wmu, const float *wsg, const float *__restrict__ mu,
+                                              const float *__restrict__ sg, const Win w, float x, float y, float z)
+{
+    int ix = clampi(raw_cell<GEO>(x, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    int iy = clampi(raw_cell<GEO>(y, p.y0, p.res, p.inv_res), 0, p.G - 1);
+    float m, s;
+    if (LDSWIN) {
+        const int e = clampi(iy - w.wy0, 0, p.WN - 1) * p.WN + clampi(ix - w.wx0, 0, p.WN - 1);
+        m = wmu[e]; s = wsg[e];
+    } else {
+        m = mu[(size_t)iy * p.G + ix]; s = sg[(size_t)iy * p.G + ix];
+    }
+    const float slip = z * s + m;
+    return 1.0f - clampf(slip, 0.0f, 1.0f);
+}
+
 // Wave-wide butterfly reductions (ds_bpermute).  A DPP row-scan formulation was measured 0.25 us faster
 // per launch but hipcc's DPP combiner mis-folds the update_dpp + add pairs inside this kernel (wrong sums
 // on hardware, correct in an isolated test kernel), so the shuffle form stays.
@@ -319,7 +349,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     BN_STAMP(8);
 
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
-    if (LDSWIN) {
+    if (LDSWIN && !p.slip_on) {
         w = window_origin<GEO>(p, sx, sy);
         stage_window(win, map, w, p.WN, p.G, tid, kFinishThreads);
     }
@@ -353,7 +383,23 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     }
     BN_STAMP(10);
 
-    if (tid == 0) {
+    if (tid == 0 && p.slip_on) {
+        // sampled-slip mode: the optimal rollout draws a fresh slip per transit as well (mppi.py:202-214 + A9)
+        const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
+        const float *zo = p.zo ? p.zo + (size_t)b * T : nullptr;
+        float x = sx, y = sy, th = sth;
+        float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
+        for (int t = 0; t < T; ++t) {
+            const float trav = trav_sampled<GEO, false>(p, nullptr, nullptr, map, sg, w, x, y, slip_normal(p, zo, t, b, 0xffffffffu, t, 2));
+            float sn, cs;
+            sincos_spec(th, sn, cs);
+            const float xn = x + ((trav * us[2 * t]) * cs) * p.dt, yn = y + ((trav * us[2 * t]) * sn) * p.dt;
+            const float tn = th + (trav * us[2 * t + 1]) * p.dt;
+            Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+            x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
+        }
+        Xs[3 * T] = x; Xs[3 * T + 1] = y; Xs[3 * T + 2] = th;
+    } else if (tid == 0) {
         // optimal_state_seq: batch-1 rollout of U* with the same aliasing (mppi.py:202-214)
         Chain c;
         c.x = sx; c.y = sy; c.th = sth;
@@ -792,6 +838,99 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
     if (tid == 0) best_out[b] = imin;
 }
 
+// ------------------------------------------------------------------------------
+// Sampled-slip rollouts (BASELINE config 3).  The reference's MPPI cannot run with observation-mode dynamics
+// (transit returns a tuple), but its components define the semantics (A9): every
+// get_traversability call draws a fresh slip ~ Normal(mean, std)[cell] (traversability_model.py:65-69,
+// Normal.sample == normal_().mul_(std).add_(mean)), so per rollout: T draws in transit (at states 0..T-1),
+// T draws in the stage costs (at slots 0..T-1) and one in the terminal cost: (2T+1) K draws per solve.
+// Plain layout: one wavefront per 64 rollouts, no role split (this mode is a parity case, not the bench line).
+// grid = (ceil(K/64), B), block = 64.  LDS: [ mean | std windows 2*WN*WN | mean 2T | mean*inv_var 2T | tile 2T x 65 | e 64 ]
+// ------------------------------------------------------------------------------
+template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
+__global__ __launch_bounds__(64) void rollout_sampled_kernel(const SolveParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.T, K = p.K;
+    const int wn2 = LDSWIN ? p.WN * p.WN : 0;
+    float *wmu = smem, *wsg = wmu + wn2;
+    float *ml = wsg + wn2, *mv = ml + 2 * T, *Ul = mv + 2 * T, *el = Ul + 2 * T * kUPad;
+    const int lane = threadIdx.x, b = blockIdx.y;
+    const int k = blockIdx.x * 64 + lane;
+    const bool active = k < K;
+    const int kk = active ? k : K - 1;
+    const float *__restrict__ mu = p.map + (size_t)b * p.map_stride;
+    const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
+    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (LDSWIN) {
+        w = window_origin<GEO>(p, sx, sy);
+        for (int e = lane; e < wn2; e += 64) {
+            const int r = e / p.WN, c = e - r * p.WN;
+            const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
+            wmu[e] = mu[g]; wsg[e] = sg[g];
+        }
+    }
+    for (int j = lane; j < 2 * T; j += 64) {
+        const float m = p.mean[(size_t)b * 2 * T + j];
+        ml[j] = m;
+        mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
+    }
+    if (blockIdx.x == 0 && lane < 3) p.state_copy[b * 3 + lane] = p.state[b * 3 + lane];
+    __syncthreads();
+    const size_t Kp = (size_t)p.Kp;
+    float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
+    float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
+    for (int t = 0; t < T; t += 2) produce_pair<EPS, STORE_U>(p, p.eps, b, kk, t, p.solve, ml, Ul, Ub, Kp, lane);
+    __syncthreads();
+    const float *zt = p.zt ? p.zt + (size_t)b * T * K : nullptr;
+    const float *zc = p.zc ? p.zc + (size_t)b * (T + 1) * K : nullptr;
+    float x = sx, y = sy, th = sth;
+    double Sd = 0.0, Ad = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const float u0 = Ul[(2 * t) * kUPad + lane], u1 = Ul[(2 * t + 1) * kUPad + lane];
+        const float trav = trav_sampled<GEO, LDSWIN>(p, wmu, wsg, mu, sg, w, x, y,
+                                                     slip_normal(p, zt, (size_t)t * K + kk, b, kk, t, 0));      // robot_model.py:75
+        float sn, cs;
+        sincos_spec(th, sn, cs);
+        const float xn = x + ((trav * u0) * cs) * p.dt, yn = y + ((trav * u0) * sn) * p.dt, tn = th + (trav * u1) * p.dt;
+        float *Xt = Xb + (size_t)(3 * t) * Kp;
+        Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;
+        x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
+        // stage cost on the aliased slot: its own, independent slip draw (objectives.py:50)
+        const float tc = trav_sampled<GEO, LDSWIN>(p, wmu, wsg, mu, sg, w, xn, yn,
+                                                   slip_normal(p, zc, (size_t)t * K + kk, b, kk, t, 1));
+        const float dx = xn - gx, dy = yn - gy;
+        Sd += (double)(sqrtf(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f));
+        Ad += (double)(p.lambda_ * (mv[2 * t] * u0 + mv[2 * t + 1] * u1));
+    }
+    {
+        float *Xt = Xb + (size_t)(3 * T) * Kp;
+        Xt[0] = x; Xt[Kp] = y; Xt[2 * Kp] = th;
+    }
+    const float tT = trav_sampled<GEO, LDSWIN>(p, wmu, wsg, mu, sg, w, x, y, slip_normal(p, zc, (size_t)T * K + kk, b, kk, T, 1));
+    const float dxT = x - gx, dyT = y - gy;
+    const float term = sqrtf(dxT * dxT + dyT * dyT) + (tT <= p.thr ? 1.0e4f : 0.0f);
+    const float cost = ((float)Sd + term) + (float)Ad;
+    if (active) p.cost[(size_t)b * K + k] = cost;
+    const float zz = active ? (-cost) / p.lambda_ : -INFINITY;
+    const float zmax = wave_max(zz);
+    const float e = active ? expf(zz - zmax) : 0.0f;
+    const float esum = wave_sum(e);
+    el[lane] = e;
+    __syncthreads();
+    float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+    for (int j = lane; j < 2 * T; j += 64) {
+        const float *col = Ul + j * kUPad;
+        float acc = 0.0f;
+#pragma unroll 16
+        for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
+        part[2 + j] = acc;
+    }
+    if (lane == 0) { part[0] = zmax; part[1] = esum; }
+}
+
 // ---- layout helpers -----------------------------------------------------------
 __global__ void soa_to_aos_kernel(const float *__restrict__ in, float *__restrict__ out, int K, int Kp, int R)
 {   // in (R, Kp pitch) -> out (K, R)
@@ -914,6 +1053,40 @@ hipError_t launch_finish(const SolveParams &p, hipStream_t s)
 }
 
 static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256); }
+
+template <int EPS, int GEO>
+hipError_t launch_sampled_g(const SolveParams &p, hipStream_t s)
+{
+    const bool win = p.WN > 0;
+    const size_t lds = sizeof(float) * (2 * (size_t)p.WN * p.WN + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad + 64);
+    const dim3 grid(p.nblk, p.B), block(64);
+#define BN_SL(LW, SU)                                                                                                  \
+    do { hipError_t e = ensure_lds(rollout_sampled_kernel<EPS, GEO, LW, SU>, lds); if (e != hipSuccess) return e;      \
+         rollout_sampled_kernel<EPS, GEO, LW, SU><<<grid, block, lds, s>>>(p); } while (0)
+    if (win) { if (p.U) BN_SL(true, true); else BN_SL(true, false); }
+    else { if (p.U) BN_SL(false, true); else BN_SL(false, false); }
+#undef BN_SL
+    return hipGetLastError();
+}
+
+template <int EPS>
+hipError_t launch_sampled_e(const SolveParams &p, hipStream_t s)
+{
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: return launch_sampled_g<EPS, kGeoPow2Origin0>(p, s);
+    case kGeoPow2: return launch_sampled_g<EPS, kGeoPow2>(p, s);
+    default: return launch_sampled_g<EPS, kGeoGeneral>(p, s);
+    }
+}
+
+hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s)
+{
+    switch (mode) {
+    case kEpsPhilox: return launch_sampled_e<kEpsPhilox>(p, s);
+    case kEpsKT2: return launch_sampled_e<kEpsKT2>(p, s);
+    default: return launch_sampled_e<kEpsT2K>(p, s);
+    }
+}
 
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
                       float *w, int *best, hipStream_t s)

@@ -31,7 +31,7 @@ class NativeMPPI:
                  sigmas=(0.5, 0.5), inv_var=None, lambda_: float = 0.5, u_min=(0.0, -1.0), u_max=(1.0, 1.0),
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
-                 profile: bool = False, stream: Optional[int] = None, pipeline: bool = True):
+                 profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -57,7 +57,8 @@ class NativeMPPI:
                      | (0 if lds_window else _capi.BN_FLAG_NO_LDS_WINDOW)
                      | (_capi.BN_FLAG_PROFILE if profile else 0)
                      | (_capi.BN_FLAG_PRIVATE_STREAM if stream is None else 0)
-                     | (0 if pipeline else _capi.BN_FLAG_NO_PIPELINE))
+                     | (0 if pipeline else _capi.BN_FLAG_NO_PIPELINE)
+                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0))
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
         self.store_controls = store_controls
@@ -86,6 +87,15 @@ class NativeMPPI:
     def set_map(self, risk, instance: int = -1):
         r = _f32(risk, (self.G, self.G))
         _capi.check(self._lib.bn_mppi_set_map(self._h, instance, C.c_void_p(r.ctypes.data), _capi.BN_MEM_HOST))
+
+    def set_slip_std(self, std, instance: int = -1):
+        """Sampled-slip mode: per-cell slip std; the map given to set_map is then the slip mean."""
+        r = _f32(std, (self.G, self.G))
+        _capi.check(self._lib.bn_mppi_set_slip_std(self._h, instance, C.c_void_p(r.ctypes.data), _capi.BN_MEM_HOST))
+
+    def set_slip_noise(self, zt_ptr: Optional[int], zc_ptr: Optional[int], zo_ptr: Optional[int]):
+        """Injected standard normals (device pointers): transit (B,T,K), cost (B,T+1,K), optimal rollout (B,T); None = Philox."""
+        _capi.check(self._lib.bn_mppi_set_slip_noise(self._h, C.c_void_p(zt_ptr), C.c_void_p(zc_ptr), C.c_void_p(zo_ptr)))
 
     def set_goal(self, goal, instance: int = -1):
         _capi.check(self._lib.bn_mppi_set_goal(self._h, instance, _fp(_f32(goal, (2,)))))

@@ -71,7 +71,9 @@ enum {
     BN_FLAG_NO_LDS_WINDOW = 1u << 2,   /* debug: gather the risk map from global memory      */
     BN_FLAG_PROFILE = 1u << 3,         /* record HIP events around each kernel (see bn_mppi_kernel_ms) */
     BN_FLAG_PRIVATE_STREAM = 1u << 4,  /* ignore `stream`: the library creates and owns a non-blocking stream */
-    BN_FLAG_NO_PIPELINE = 1u << 5      /* always two launches per solve (rollout, finish); see bn_mppi_solve_async */
+    BN_FLAG_NO_PIPELINE = 1u << 5,     /* always two launches per solve (rollout, finish); see bn_mppi_solve_async */
+    BN_FLAG_SAMPLED_SLIP = 1u << 6     /* BASELINE config 3: every traversability lookup of the rollouts draws
+                                          slip ~ Normal(map, slip_std)[cell]; see bn_mppi_set_slip_std */
 };
 
 /*
@@ -123,6 +125,15 @@ void bn_mppi_destroy(bn_mppi_t *h);
 /* dynamics._traversability_model._risks (traversability_model.py:24-26), (G,G)
  * row-major [iy][ix] (grid_map.py:167).  instance = -1 sets every map. */
 int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_kind where);
+/* Sampled-slip mode (BN_FLAG_SAMPLED_SLIP): the map set with bn_mppi_set_map is the slip MEAN and this the slip
+ * STD per cell, (G,G); every get_traversability of the rollouts then evaluates 1 - clamp(z*std + mean, 0, 1) with
+ * a fresh standard normal z (the observation-mode branch, traversability_model.py:65-69): T draws in transit,
+ * T+1 in the stage/terminal costs per rollout, T in the optimal rollout.  The reference's own MPPI cannot run in
+ * this mode; the semantics are those of its components. */
+int bn_mppi_set_slip_std(bn_mppi_t *h, int32_t instance, const float *std, bn_mem_kind where);
+/* Optional injected draws for the next solves (device pointers, k fastest): transit (B,T,K), cost (B,T+1,K),
+ * optimal rollout (B,T).  NULL (default) = the library's Philox stream. */
+int bn_mppi_set_slip_noise(bn_mppi_t *h, const float *zt_device, const float *zc_device, const float *zo_device);
 /* objectives._goal_pos (objectives.py:26).  instance = -1 sets every instance. */
 int bn_mppi_set_goal(bn_mppi_t *h, int32_t instance, const float goal_host[2]);
 /* _previous_action_seq (mppi.py:116,217): (T,2) host array; NULL resets it to zero. */

@@ -129,3 +129,15 @@ def dwa(p: OracleParams, R, state, actions, sub_goal=None):
     lib().oracle_dwa.restype = C.c_int32
     best = lib().oracle_dwa(C.byref(p), _fp(R), _fp(state), _fp(actions), C.c_int32(NA), _fp(sg), _fp(X), _fp(cost), _fp(w))
     return dict(X=X, cost=cost, w=w, best=int(best))
+
+
+def solve_sampled(p: OracleParams, MU, SG, state, mean, eps, zt, zc, zo):
+    """MPPI solve with sampled slip (BASELINE config 3); zt (K,T), zc (K,T+1), zo (T) standard normals."""
+    K, T, G = p.K, p.T, p.G
+    MU = _f32(MU, (G, G)); SG = _f32(SG, (G, G)); state = _f32(state, (3,)); mean = _f32(mean, (T, 2))
+    eps = _f32(eps, (K, T, 2)); zt = _f32(zt, (K, T)); zc = _f32(zc, (K, T + 1)); zo = _f32(zo, (T,))
+    out = dict(U=np.empty((K, T, 2), np.float32), X=np.empty((K, T + 1, 3), np.float32), cost=np.empty(K, np.float32),
+               w=np.empty(K, np.float32), Ustar=np.empty((T, 2), np.float32), Xstar=np.empty((T + 1, 3), np.float32))
+    lib().oracle_solve_sampled(C.byref(p), _fp(MU), _fp(SG), _fp(state), _fp(mean), _fp(eps), _fp(zt), _fp(zc), _fp(zo),
+                               _fp(out["U"]), _fp(out["X"]), _fp(out["cost"]), _fp(out["w"]), _fp(out["Ustar"]), _fp(out["Xstar"]))
+    return out

@@ -182,9 +182,81 @@ def run_dwa_case():
     print(f"dwa            G={G} T={T} candidates=100 solves=3 -> {os.path.getsize(p_)/1024:.0f} KiB")
 
 
+def run_sampled_case():
+    """BASELINE config 3's semantics from the reference's own components: UnicycleModel / Objectives in
+    OBSERVATION mode (slip drawn per lookup, traversability_model.py:65-69) driven by the loop of mppi.py:150-214.
+    The reference's MPPI class cannot run this mode itself (transit returns a tuple), so the loop below is the
+    generator's; every traversability, transit and cost evaluation is the reference's.  Each Normal.sample() is
+    captured as its standard normal z by replaying the generator state (checked: z*std+mean == the sample)."""
+    G, res, K, T, thr, lam = 64, 0.5, 256, 20, 0.3, 0.5
+    sig = torch.tensor([0.5, 0.5])
+    goal = torch.tensor([24.0, 24.0])
+    mean_map = smooth_risk_map(G, 8) * 0.8
+    std_map = slip_std_map(G, 8)
+    tens = {"heights": torch.zeros(G, G), "slopes": torch.zeros(G, G), "t_classes": torch.zeros(G, G), "colors": torch.zeros(3, G, G)}
+    dist = {"latent_models": Normal(mean_map, std_map), "predictions": Normal(mean_map, std_map)}
+    gm = GridMap(grid_size=G, resolution=res, tensors=tens, distributions=dist, instance_name="synthetic", device="cpu")
+    dyn = UnicycleModel(gm, ModelConfig(mode="observation"), device="cpu")
+    obj = Objectives(dyn, goal_pos=goal, stuck_threshold=thr)
+    drawn = []
+    real_normal = torch.normal
+
+    def capturing_normal(loc, scale, *a, **k):
+        st = torch.get_rng_state()
+        sample = real_normal(loc, scale, *a, **k)
+        after = torch.get_rng_state()
+        torch.set_rng_state(st)
+        z = torch.empty_like(sample).normal_()
+        assert torch.equal(torch.get_rng_state(), after) and torch.equal(z * scale + loc, sample), "draw replay drifted"
+        drawn.append(z.reshape(-1).clone())
+        return sample
+
+    torch.normal = capturing_normal
+    try:
+        torch.manual_seed(77)
+        state = torch.tensor([9.0, 8.5, 0.6])
+        mean = (torch.randn(T, 2) * 0.2 + torch.tensor([0.6, 0.0])).clamp(torch.tensor([0.0, -1.0]), torch.tensor([1.0, 1.0]))
+        eps = torch.randn(K, T, 2)
+        U = torch.clamp(mean + eps * sig, dyn.min_action, dyn.max_action)            # mppi.py:146-153
+        inv_cov = torch.inverse(torch.diag(sig ** 2))
+        X = torch.zeros(K, T + 1, 3)
+        X[:, 0, :] = state
+        for t in range(T):                                                            # mppi.py:158-163
+            X[:, t + 1, :], _ = dyn.transit(X[:, t, :], U[:, t, :])
+        zt = torch.stack(drawn, 1); drawn.clear()
+        stage, act = torch.zeros(K, T), torch.zeros(K, T)
+        for t in range(T):                                                            # mppi.py:168-181
+            stage[:, t] = obj.stage_cost(X[:, t, :], U[:, t, :])
+            act[:, t] = mean[t] @ inv_cov @ U[:, t].T
+        term = obj.terminal_cost(X[:, -1, :])
+        zc = torch.stack(drawn, 1); drawn.clear()
+        cost = torch.sum(stage, dim=1) + term + torch.sum(lam * act, dim=1)           # mppi.py:184-190
+        w = torch.softmax(-cost / lam, dim=0)
+        Ustar = torch.sum(w.view(K, 1, 1) * U, dim=0)                                 # mppi.py:193-199
+        Xs = torch.zeros(1, T + 1, 3)
+        Xs[:, 0, :] = state
+        for t in range(T):                                                            # mppi.py:202-214
+            Xs[:, t + 1, :], _ = dyn.transit(Xs[:, t, :], Ustar[t].unsqueeze(0))
+        zo = torch.cat(drawn); drawn.clear()
+    finally:
+        torch.normal = real_normal
+    assert zt.shape == (K, T) and zc.shape == (K, T + 1) and zo.shape == (T,)
+    out = dict(G=G, res=res, K=K, T=T, thr=thr, lam=lam, sigmas=sig.numpy(), goal=goal.numpy(), MU=mean_map.numpy(), SG=std_map.numpy(),
+               inv_var=torch.diagonal(inv_cov).numpy().copy(), x_limits=np.asarray(gm.x_limits, np.float64),
+               y_limits=np.asarray(gm.y_limits, np.float64), u_min=dyn.min_action.numpy().copy(), u_max=dyn.max_action.numpy().copy(),
+               state=state.numpy(), mean=mean.numpy(), eps=eps.numpy(), zt=zt.numpy(), zc=zc.numpy(), zo=zo.numpy(), U=U.numpy(),
+               X=X.numpy(), cost=cost.numpy(), w=w.numpy(), Ustar=Ustar.numpy(), Xstar=Xs[0].numpy(), torch_version=torch.__version__)
+    path = os.path.join(HERE, "sampled.npz")
+    np.savez_compressed(path, **out)
+    print(f"sampled        G={G} K={K} T={T} max_w={float(w.max()):.3f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     pi = math.pi
+    if sys.argv[1:] == ["sampled"]:
+        return run_sampled_case()
     run_riskmap_case()
+    run_sampled_case()
     run_dwa_case()
     # config 1 of BASELINE.json: test_mppi.py object graph, synthetic 64x64 map, int64 goal (test_mppi.py:132-133)
     run_case("c1_basic", G=64, res=0.5, K=128, T=20, risk_mean=smooth_risk_map(64, 0),
