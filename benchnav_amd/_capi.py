@@ -46,6 +46,7 @@ SYMBOLS = {
     "bn_mppi_destroy": (None, [_H]),
     "bn_mppi_set_map": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int]),
     "bn_mppi_set_slip_std": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int]),
+    "bn_mppi_get_slip_noise": (C.c_int, [_H, C.c_int32, C.c_uint64, _FP, _FP, _FP]),
     "bn_mppi_set_slip_noise": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bn_mppi_set_goal": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_set_mean": (C.c_int, [_H, C.c_int32, _FP]),

@@ -127,4 +127,15 @@ __device__ __forceinline__ void philox_eps_pair(uint64_t seed, uint64_t solve, u
     box_muller(r.z, r.w, e[2], e[3]);   // step 2*pair+1
 }
 
+// Slip stream of the sampled-slip mode (BASELINE config 3): own key, same counter layout.  Block j of rollout k
+// holds the transit draws of steps 2j, 2j+1 and the cost draws of slots 2j, 2j+1; rollout index 0xffffffff is the
+// optimal rollout, whose block j holds the transit draws of steps 4j .. 4j+3.
+__device__ __forceinline__ void philox_slip_block(uint64_t seed, uint64_t solve, uint32_t b, uint32_t k, uint32_t j, float z[4])
+{
+    const u32x4 r = philox4x32_10(u32x4{k, j, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
+                                  (uint32_t)seed ^ 0x534c4950u, (uint32_t)(seed >> 32));
+    box_muller(r.x, r.y, z[0], z[1]);
+    box_muller(r.z, r.w, z[2], z[3]);
+}
+
 }  // namespace bn

@@ -721,6 +721,23 @@ int bn_mppi_get_philox_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_inde
     return BN_OK;
 }
 
+int bn_mppi_get_slip_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_index, float *zt_host, float *zc_host, float *zo_host)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (!zt_host || !zc_host || !zo_host) return fail(BN_ERR_INVALID, "null output");
+    if (!h->p.slip_on) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_SAMPLED_SLIP");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    const size_t K = h->p.K, T = h->p.T, nt = K * T, nc = K * (T + 1);
+    if (int rc = ensure_scratch(h, (nt + nc + T) * 4)) return rc;
+    float *zt = h->d_scratch, *zc = zt + nt, *zo = zc + nc;
+    BN_HIP(bn::launch_philox_slip(zt, zc, zo, h->p.seed, solve_index, instance, (int)K, (int)T, h->stream));
+    BN_HIP(hipMemcpyAsync(zt_host, zt, nt * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipMemcpyAsync(zc_host, zc, nc * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipMemcpyAsync(zo_host, zo, T * 4, hipMemcpyDeviceToHost, h->stream));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    return BN_OK;
+}
+
 int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *states_host, float *weights_host)
 {
     if (int rc = check_instance(h, instance, false)) return rc;

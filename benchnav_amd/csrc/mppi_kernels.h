@@ -85,6 +85,7 @@ hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *s
 hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s);   // (T1,3,Kp)->(K,T1,3)
 hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int Kp, int T, hipStream_t s);  // (T,2,Kp)->(K,T,2)
 hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int Kp, int T1, hipStream_t s);
+hipError_t launch_philox_slip(float *zt, float *zc, float *zo, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s);   // (K,T), (K,T+1), (T)
 hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s);
 
 }  // namespace bn

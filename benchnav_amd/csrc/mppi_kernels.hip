@@ -197,34 +197,57 @@ __device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, floa
     return r;
 }
 
-// Sampled-slip helpers (BASELINE config 3, see rollout_sampled_kernel): one standard normal per lookup, from the
-// caller's arrays or the Philox stream, and the observation-mode traversability 1 - clamp(z*std + mean, 0, 1).
-__device__ __forceinline__ float slip_normal(const SolveParams &p, const float *z, size_t idx, uint32_t b, uint32_t k,
-                                             uint32_t t, uint32_t kind)
+// Sampled-slip helpers (BASELINE config 3, see rollout_sampled_kernel): every lookup evaluates the observation-mode
+// traversability 1 - clamp(z*std + mean, 0, 1) (traversability_model.py:65-69) with its own standard normal z.
+__device__ __forceinline__ float trav_from_slip(float mu, float sd, float z)
 {
-    if (z) return z[idx];
-    const u32x4 q = philox4x32_10(u32x4{k, t, (uint32_t)p.solve ^ (b << 20), 0x534c4950u + kind}, (uint32_t)p.seed,
-                                  (uint32_t)(p.seed >> 32));
-    float z0, z1;
-    box_muller(q.x, q.y, z0, z1);
-    return z0;
+    const float slip = z * sd + mu;                   // Normal.sample(): normal_(0,1).mul_(std).add_(mean)
+    return 1.0f - clampf(slip, 0.0f, 1.0f);
 }
 
+// Cell of a position of any magnitude, as map index (iy * G + ix) or, with the window, window index.
 template <int GEO, bool LDSWIN>
-__device__ __forceinline__ float trav_sampled(const SolveParams &p, const float *wmu, const float *wsg, const float *__restrict__ mu,
-                                              const float *__restrict__ sg, const Win w, float x, float y, float z)
+__device__ __forceinline__ int slip_cell_safe(const SolveParams &p, const Win w, float x, float y)
 {
-    int ix = clampi(raw_cell<GEO>(x, p.x0, p.res, p.inv_res), 0, p.G - 1);
-    int iy = clampi(raw_cell<GEO>(y, p.y0, p.res, p.inv_res), 0, p.G - 1);
-    float m, s;
-    if (LDSWIN) {
-        const int e = clampi(iy - w.wy0, 0, p.WN - 1) * p.WN + clampi(ix - w.wx0, 0, p.WN - 1);
-        m = wmu[e]; s = wsg[e];
-    } else {
-        m = mu[(size_t)iy * p.G + ix]; s = sg[(size_t)iy * p.G + ix];
-    }
-    const float slip = z * s + m;
-    return 1.0f - clampf(slip, 0.0f, 1.0f);
+    const int ix = clampi(raw_cell<GEO>(x, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    const int iy = clampi(raw_cell<GEO>(y, p.y0, p.res, p.inv_res), 0, p.G - 1);
+    if (LDSWIN) return clampi(iy - w.wy0, 0, p.WN - 1) * p.WN + clampi(ix - w.wx0, 0, p.WN - 1);
+    return iy * p.G + ix;
+}
+
+// Window cell of a position within (or a step beyond) the map limits, float domain as in trav_window.
+template <int GEO>
+__device__ __forceinline__ int slip_cell_window(const SolveParams &p, const Win w, float x, float y)
+{
+    v2f q;
+    const v2f xy = {x, y}, ir = {p.inv_res, p.inv_res}, nw = {-w.fx0, -w.fy0};
+    if (GEO == kGeoPow2Origin0) q = __builtin_elementwise_fma(xy, ir, nw);
+    else if (GEO == kGeoPow2) q = __builtin_elementwise_fma(xy - v2f{p.x0, p.y0}, ir, nw);
+    else q = v2f{(x - p.x0) / p.res, (y - p.y0) / p.res} + nw;
+    const float li = clampf(floorf(q.x), 0.0f, w.fwm1);
+    const float lj = clampf(floorf(q.y), 0.0f, w.fwm1);
+    return (int)__builtin_fmaf(lj, w.fwn, li);
+}
+
+// One observation-mode transit (robot_model.py:59-100) of the sampled-slip chain on the LDS window of (mean, std)
+// pairs: state (x, y, th) with heading (sn, cs) and window cell e advances; (xn, yn, tn) is what slot t keeps.
+struct SlipChain { float x, y, th, sn, cs; int e; };
+
+template <int GEO, bool FIRST>
+__device__ __forceinline__ void slip_chain_step(const SolveParams &p, const float2 *win2, const Win w, SlipChain &c, float u0,
+                                                float u1, float z, float &xn, float &yn, float &tn)
+{
+    const float2 ms = win2[c.e];
+    const float trav = trav_from_slip(ms.x, ms.y, z);                  // robot_model.py:75
+    const float tv = trav * u0;
+    tn = c.th + (trav * u1) * p.dt;
+    xn = c.x + (tv * c.cs) * p.dt;
+    yn = c.y + (tv * c.sn) * p.dt;
+    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);
+    c.x = clampf(xn, p.x0, p.x_hi);
+    c.y = clampf(yn, p.y0, p.y_hi);
+    sincos_spec(c.th, c.sn, c.cs);
+    c.e = slip_cell_window<GEO>(p, w, c.x, c.y);
 }
 
 // Wave-wide butterfly reductions (ds_bpermute).  A DPP row-scan formulation was measured 0.25 us faster
@@ -296,17 +319,22 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         m = wave_max(L.mi);
         const float f = lane < nblk ? expf(L.mi - m) : 0.0f;       // scale of block `lane`; 0 past nblk
         S = wave_sum(L.si * f);
+        // scale of block i = lane i's f, read with v_readlane (ignores EXEC): only the lanes with jj < 2T enter the
+        // loop below, and a ds_bpermute shuffle returns nothing from the lanes that did not
+        const int fb = __float_as_int(f);
+#define BN_SCALE(i) __int_as_float(__builtin_amdgcn_readlane(fb, (i)))
         for (int jj = tid; jj < 2 * T; jj += kFinishThreads) {
             float acc = 0.0f;
             if (jj == L.j) {
 #pragma unroll
-                for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], __shfl(f, i), acc);   // f == 0 past nblk
-                for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], __shfl(f, i), acc);
+                for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], BN_SCALE(i), acc);   // f == 0 past nblk
+                for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], BN_SCALE(i), acc);
             } else {
-                for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], __shfl(f, i), acc);
+                for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], BN_SCALE(i), acc);
             }
             us[jj] = acc / S;
         }
+#undef BN_SCALE
     } else {
         float mm = -INFINITY;
         for (int i = tid; i < nblk; i += kFinishThreads) mm = fmaxf(mm, part[(size_t)i * PS]);
@@ -383,22 +411,58 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     }
     BN_STAMP(10);
 
-    if (tid == 0 && p.slip_on) {
-        // sampled-slip mode: the optimal rollout draws a fresh slip per transit as well (mppi.py:202-214 + A9)
+    if (p.slip_on) {
+        // sampled-slip mode: the optimal rollout draws a fresh slip per transit as well (mppi.py:202-214 with
+        // traversability_model.py:65-69).  Draws and the (mean, std) window are staged by all threads first.
         const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
-        const float *zo = p.zo ? p.zo + (size_t)b * T : nullptr;
-        float x = sx, y = sy, th = sth;
-        float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
-        for (int t = 0; t < T; ++t) {
-            const float trav = trav_sampled<GEO, false>(p, nullptr, nullptr, map, sg, w, x, y, slip_normal(p, zo, t, b, 0xffffffffu, t, 2));
-            float sn, cs;
-            sincos_spec(th, sn, cs);
-            const float xn = x + ((trav * us[2 * t]) * cs) * p.dt, yn = y + ((trav * us[2 * t]) * sn) * p.dt;
-            const float tn = th + (trav * us[2 * t + 1]) * p.dt;
-            Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
-            x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
+        float *zol = red + kFinishThreads;                       // T + 4 draws
+        float2 *win2 = reinterpret_cast<float2 *>((reinterpret_cast<uintptr_t>(zol + ((T + 7) & ~3)) + 7) & ~(uintptr_t)7);
+        if (p.zo) {
+            for (int t = tid; t < T; t += kFinishThreads) zol[t] = p.zo[(size_t)b * T + t];
+        } else {
+            for (int j = tid; 4 * j < T; j += kFinishThreads) philox_slip_block(p.seed, p.solve, (uint32_t)b, 0xffffffffu, (uint32_t)j, zol + 4 * j);
         }
-        Xs[3 * T] = x; Xs[3 * T + 1] = y; Xs[3 * T + 2] = th;
+        if (LDSWIN) {
+            w = window_origin<GEO>(p, sx, sy);
+            for (int e = tid; e < p.WN * p.WN; e += kFinishThreads) {
+                const int r = e / p.WN, c = e - r * p.WN;
+                const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
+                win2[e] = make_float2(map[g], sg[g]);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
+            float xn, yn, tn;
+            if (LDSWIN) {
+                SlipChain c;
+                c.x = sx; c.y = sy; c.th = sth;
+                sincos_spec(c.th, c.sn, c.cs);
+                c.e = slip_cell_safe<GEO, true>(p, w, sx, sy);
+                for (int t = 0; t < T; ++t) {
+                    if (t == 0) slip_chain_step<GEO, true>(p, win2, w, c, us[0], us[1], zol[0], xn, yn, tn);
+                    else slip_chain_step<GEO, false>(p, win2, w, c, us[2 * t], us[2 * t + 1], zol[t], xn, yn, tn);
+                    Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+                }
+                Xs[3 * T] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
+            } else {
+                float x = sx, y = sy, th = sth;
+                for (int t = 0; t < T; ++t) {
+                    const int e = slip_cell_safe<GEO, false>(p, w, x, y);
+                    const float trav = trav_from_slip(map[e], sg[e], zol[t]);
+                    float sn, cs;
+                    sincos_spec(th, sn, cs);
+                    xn = x + ((trav * us[2 * t]) * cs) * p.dt; yn = y + ((trav * us[2 * t]) * sn) * p.dt;
+                    tn = th + (trav * us[2 * t + 1]) * p.dt;
+                    Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+                    x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
+                }
+                Xs[3 * T] = x; Xs[3 * T + 1] = y; Xs[3 * T + 2] = th;
+            }
+        }
+    }
+    if (p.slip_on && tid < 64) {
+        // wave 0: thread 0 ran the sampled chain above
     } else if (tid == 0) {
         // optimal_state_seq: batch-1 rollout of U* with the same aliasing (mppi.py:202-214)
         Chain c;
@@ -839,22 +903,178 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
 }
 
 // ------------------------------------------------------------------------------
-// Sampled-slip rollouts (BASELINE config 3).  The reference's MPPI cannot run with observation-mode dynamics
-// (transit returns a tuple), but its components define the semantics (A9): every
-// get_traversability call draws a fresh slip ~ Normal(mean, std)[cell] (traversability_model.py:65-69,
-// Normal.sample == normal_().mul_(std).add_(mean)), so per rollout: T draws in transit (at states 0..T-1),
-// T draws in the stage costs (at slots 0..T-1) and one in the terminal cost: (2T+1) K draws per solve.
-// Plain layout: one wavefront per 64 rollouts, no role split (this mode is a parity case, not the bench line).
-// grid = (ceil(K/64), B), block = 64.  LDS: [ mean | std windows 2*WN*WN | mean 2T | mean*inv_var 2T | tile 2T x 65 | e 64 ]
+// Sampled-slip rollouts (BASELINE config 3: "GP slip-regressor mean+var sampled per step").  The map holds the slip
+// MEAN, slip_std its STD; every get_traversability is the observation-mode branch of traversability_model.py:65-69,
+// 1 - clamp(Normal(mean, std)[cell].sample(), 0, 1), with its own draw: T in transit (robot_model.py:75), T+1 in the
+// stage / terminal costs (objectives.py:50) per rollout.  The draws do not depend on the state, so they are
+// produced up front, in parallel, and only the recurrence itself stays serial:
+//   phase 1  8 waves   controls (noise -> clamp) and slip draws of all steps -> LDS tiles (Philox or injected)
+//   phase 2  wave 0    the T-step chain on the LDS window of (mean, std) pairs; slot rows -> LDS
+//            wave 1    control cost (fp64, step order)
+//   phase 3  8 waves   per slot row: trajectory stores, sampled stage cost -> LDS (overwrites its draw)
+//   phase 4  wave 0    stage-cost sum (fp64, step order), rollout cost, softmin statistics; all: weighted control sums
+// The transit lookup of state t+1 and the stage-cost lookup of slot t hit the same cell (the un-clamped slot and
+// its clamped successor index alike, grid_map.py:209), so the chain hands its cell index on with the slot row.
+// grid = (ceil(K/64), B), block = 512, lane = rollout.
+// LDS: [ slot rows (T+1) x 64 float4 | window WN^2 float2 | Zt TP x 64 | Zc TP x 64 | controls 2T x 65 | mean 2T |
+//        mean*inv_var 2T | e 64 | control cost 64 ],  TP = T+1 rounded up to even.
 // ------------------------------------------------------------------------------
-template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
-__global__ __launch_bounds__(64) void rollout_sampled_kernel(const SolveParams p)
+constexpr int kSampledWaves = 8;
+constexpr int kSampledThreads = 64 * kSampledWaves;
+
+__host__ __device__ inline size_t sampled_lds_floats(int T, int WN)
+{
+    const size_t TP = (size_t)((T + 2) & ~1);
+    return 4 * 64 * (size_t)(T + 1) + 2 * (size_t)WN * WN + 2 * 64 * TP + 2 * (size_t)T * kUPad + 4 * (size_t)T + 128;
+}
+
+template <int EPS, int GEO, bool STORE_U>
+__global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const SolveParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.T, K = p.K, WN2 = p.WN * p.WN;
+    const int TP = (T + 2) & ~1;
+    float4 *XL = reinterpret_cast<float4 *>(smem);
+    float2 *win2 = reinterpret_cast<float2 *>(smem + 4 * 64 * (T + 1));
+    float *Zt = reinterpret_cast<float *>(win2 + WN2), *Zc = Zt + 64 * TP;
+    float *Ul = Zc + 64 * TP, *ml = Ul + 2 * T * kUPad, *mv = ml + 2 * T, *el = mv + 2 * T, *ad = el + 64;
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = blockIdx.x * 64 + lane;
+    const bool active = k < K;
+    const int kk = active ? k : K - 1;
+    const float *__restrict__ mu = p.map + (size_t)b * p.map_stride;
+    const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
+    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
+    const Win w = window_origin<GEO>(p, sx, sy);
+    const size_t Kp = (size_t)p.Kp;
+    float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
+    float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
+
+    // ---- phase 0: window of (mean, std) pairs, warm-start mean ----
+    for (int e = tid; e < WN2; e += kSampledThreads) {
+        const int r = e / p.WN, c = e - r * p.WN;
+        const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
+        win2[e] = make_float2(mu[g], sg[g]);
+    }
+    for (int j = tid; j < 2 * T; j += kSampledThreads) {
+        const float m = p.mean[(size_t)b * 2 * T + j];
+        ml[j] = m;
+        mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
+    }
+    if (blockIdx.x == 0 && tid < 3) p.state_copy[b * 3 + tid] = p.state[b * 3 + tid];
+    __syncthreads();
+
+    // ---- phase 1: controls and slip draws of every step ----
+    {
+        const int nE = (T + 1) >> 1, nS = TP >> 1;
+        for (int q = wid; q < nE + nS; q += kSampledWaves) {
+            if (q < nE) {
+                produce_pair<EPS, STORE_U>(p, p.eps, b, kk, 2 * q, p.solve, ml, Ul, Ub, Kp, lane);
+            } else {
+                const int r0 = 2 * (q - nE), r1 = r0 + 1;
+                float z[4];
+                if (p.zt) {
+                    z[0] = r0 < T ? p.zt[((size_t)b * T + r0) * K + kk] : 0.0f;
+                    z[1] = r1 < T ? p.zt[((size_t)b * T + r1) * K + kk] : 0.0f;
+                    z[2] = r0 <= T ? p.zc[((size_t)b * (T + 1) + r0) * K + kk] : 0.0f;
+                    z[3] = r1 <= T ? p.zc[((size_t)b * (T + 1) + r1) * K + kk] : 0.0f;
+                } else {
+                    philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(q - nE), z);
+                }
+                Zt[r0 * 64 + lane] = z[0]; Zt[r1 * 64 + lane] = z[1];
+                Zc[r0 * 64 + lane] = z[2]; Zc[r1 * 64 + lane] = z[3];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: the chain (wave 0) and the control cost (wave 1) ----
+    if (wid == 0) {
+        SlipChain c;
+        c.x = sx; c.y = sy; c.th = sth;                                   // mppi.py:160
+        sincos_spec(c.th, c.sn, c.cs);
+        c.e = slip_cell_safe<GEO, true>(p, w, sx, sy);
+        float xn, yn, tn;
+        slip_chain_step<GEO, true>(p, win2, w, c, Ul[lane], Ul[kUPad + lane], Zt[lane], xn, yn, tn);
+        XL[lane] = make_float4(xn, yn, tn, __int_as_float(c.e));
+        int t = 1;
+        for (; t + 4 <= T; t += 4) {                  // controls and draws of four steps read up front: LDS latency off the chain
+            float uq[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uq[i][0] = Ul[(2 * (t + i)) * kUPad + lane]; uq[i][1] = Ul[(2 * (t + i) + 1) * kUPad + lane];
+                uq[i][2] = Zt[(t + i) * 64 + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                slip_chain_step<GEO, false>(p, win2, w, c, uq[i][0], uq[i][1], uq[i][2], xn, yn, tn);
+                __builtin_amdgcn_sched_barrier(0);
+                XL[(t + i) * 64 + lane] = make_float4(xn, yn, tn, __int_as_float(c.e));
+            }
+        }
+        for (; t < T; ++t) {
+            slip_chain_step<GEO, false>(p, win2, w, c, Ul[(2 * t) * kUPad + lane], Ul[(2 * t + 1) * kUPad + lane], Zt[t * 64 + lane],
+                                        xn, yn, tn);
+            XL[t * 64 + lane] = make_float4(xn, yn, tn, __int_as_float(c.e));
+        }
+        XL[T * 64 + lane] = make_float4(c.x, c.y, c.th, __int_as_float(c.e));       // slot T: clamped, wrapped
+    } else if (wid == 1) {
+        double Ad = 0.0;
+        for (int t = 0; t < T; ++t)
+            Ad += (double)(p.lambda_ * (mv[2 * t] * Ul[(2 * t) * kUPad + lane] + mv[2 * t + 1] * Ul[(2 * t + 1) * kUPad + lane]));   // mppi.py:175-181
+        ad[lane] = (float)Ad;
+    }
+    __syncthreads();
+
+    // ---- phase 3: slot rows -> trajectory stores and sampled stage / terminal cost ----
+    for (int t = wid; t <= T; t += kSampledWaves) {
+        const float4 o = XL[t * 64 + lane];
+        float *Xt = Xb + (size_t)(3 * t) * Kp;
+        Xt[0] = o.x; Xt[Kp] = o.y; Xt[2 * Kp] = o.z;
+        const float2 ms = win2[__float_as_int(o.w)];
+        const float tc = trav_from_slip(ms.x, ms.y, Zc[t * 64 + lane]);                // objectives.py:50
+        const float dx = o.x - gx, dy = o.y - gy;
+        Zc[t * 64 + lane] = sqrtf(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f);  // objectives.py:46-53
+    }
+    __syncthreads();
+
+    // ---- phase 4: rollout cost and the workgroup's softmin statistics ----
+    if (wid == 0) {
+        double Sd = 0.0;
+        for (int t = 0; t < T; ++t) Sd += (double)Zc[t * 64 + lane];
+        const float cost = ((float)Sd + Zc[T * 64 + lane]) + ad[lane];                 // mppi.py:184-190
+        if (active) p.cost[(size_t)b * K + k] = cost;
+        const float zz = active ? (-cost) / p.lambda_ : -INFINITY;
+        const float zmax = wave_max(zz);
+        const float e = active ? expf(zz - zmax) : 0.0f;
+        const float esum = wave_sum(e);
+        el[lane] = e;
+        if (lane == 0) {
+            float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+            part[0] = zmax; part[1] = esum;
+        }
+    }
+    __syncthreads();
+    float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+    for (int j = tid; j < 2 * T; j += kSampledThreads) {
+        const float *col = Ul + j * kUPad;
+        float acc = 0.0f;
+#pragma unroll 16
+        for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
+        part[2 + j] = acc;
+    }
+}
+
+// The same solve without the LDS window (BN_FLAG_NO_LDS_WINDOW, or a window/horizon too large for the LDS):
+// one wave per 64 rollouts, lookups from global memory, draws made in line.
+template <int EPS, int GEO, bool STORE_U>
+__global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T, K = p.K;
-    const int wn2 = LDSWIN ? p.WN * p.WN : 0;
-    float *wmu = smem, *wsg = wmu + wn2;
-    float *ml = wsg + wn2, *mv = ml + 2 * T, *Ul = mv + 2 * T, *el = Ul + 2 * T * kUPad;
+    float *ml = smem, *mv = ml + 2 * T, *Ul = mv + 2 * T, *el = Ul + 2 * T * kUPad;
     const int lane = threadIdx.x, b = blockIdx.y;
     const int k = blockIdx.x * 64 + lane;
     const bool active = k < K;
@@ -863,15 +1083,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_kernel(const SolveParams p
     const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
     const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
-    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
-    if (LDSWIN) {
-        w = window_origin<GEO>(p, sx, sy);
-        for (int e = lane; e < wn2; e += 64) {
-            const int r = e / p.WN, c = e - r * p.WN;
-            const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
-            wmu[e] = mu[g]; wsg[e] = sg[g];
-        }
-    }
+    const Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     for (int j = lane; j < 2 * T; j += 64) {
         const float m = p.mean[(size_t)b * 2 * T + j];
         ml[j] = m;
@@ -884,14 +1096,19 @@ __global__ __launch_bounds__(64) void rollout_sampled_kernel(const SolveParams p
     float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
     for (int t = 0; t < T; t += 2) produce_pair<EPS, STORE_U>(p, p.eps, b, kk, t, p.solve, ml, Ul, Ub, Kp, lane);
     __syncthreads();
-    const float *zt = p.zt ? p.zt + (size_t)b * T * K : nullptr;
-    const float *zc = p.zc ? p.zc + (size_t)b * (T + 1) * K : nullptr;
     float x = sx, y = sy, th = sth;
+    float zq[4] = {0.f, 0.f, 0.f, 0.f};
     double Sd = 0.0, Ad = 0.0;
     for (int t = 0; t < T; ++t) {
+        if (p.zt) {
+            zq[t & 1] = p.zt[((size_t)b * T + t) * K + kk];
+            zq[2 + (t & 1)] = p.zc[((size_t)b * (T + 1) + t) * K + kk];
+        } else if ((t & 1) == 0) {
+            philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(t >> 1), zq);
+        }
         const float u0 = Ul[(2 * t) * kUPad + lane], u1 = Ul[(2 * t + 1) * kUPad + lane];
-        const float trav = trav_sampled<GEO, LDSWIN>(p, wmu, wsg, mu, sg, w, x, y,
-                                                     slip_normal(p, zt, (size_t)t * K + kk, b, kk, t, 0));      // robot_model.py:75
+        const int e = slip_cell_safe<GEO, false>(p, w, x, y);
+        const float trav = trav_from_slip(mu[e], sg[e], zq[t & 1]);                                     // robot_model.py:75
         float sn, cs;
         sincos_spec(th, sn, cs);
         const float xn = x + ((trav * u0) * cs) * p.dt, yn = y + ((trav * u0) * sn) * p.dt, tn = th + (trav * u1) * p.dt;
@@ -899,8 +1116,8 @@ __global__ __launch_bounds__(64) void rollout_sampled_kernel(const SolveParams p
         Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;
         x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
         // stage cost on the aliased slot: its own, independent slip draw (objectives.py:50)
-        const float tc = trav_sampled<GEO, LDSWIN>(p, wmu, wsg, mu, sg, w, xn, yn,
-                                                   slip_normal(p, zc, (size_t)t * K + kk, b, kk, t, 1));
+        const int ec = slip_cell_safe<GEO, false>(p, w, xn, yn);
+        const float tc = trav_from_slip(mu[ec], sg[ec], zq[2 + (t & 1)]);
         const float dx = xn - gx, dy = yn - gy;
         Sd += (double)(sqrtf(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f));
         Ad += (double)(p.lambda_ * (mv[2 * t] * u0 + mv[2 * t + 1] * u1));
@@ -909,7 +1126,10 @@ __global__ __launch_bounds__(64) void rollout_sampled_kernel(const SolveParams p
         float *Xt = Xb + (size_t)(3 * T) * Kp;
         Xt[0] = x; Xt[Kp] = y; Xt[2 * Kp] = th;
     }
-    const float tT = trav_sampled<GEO, LDSWIN>(p, wmu, wsg, mu, sg, w, x, y, slip_normal(p, zc, (size_t)T * K + kk, b, kk, T, 1));
+    if (p.zt) zq[2 + (T & 1)] = p.zc[((size_t)b * (T + 1) + T) * K + kk];
+    else if ((T & 1) == 0) philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(T >> 1), zq);
+    const int eT = slip_cell_safe<GEO, false>(p, w, x, y);
+    const float tT = trav_from_slip(mu[eT], sg[eT], zq[2 + (T & 1)]);
     const float dxT = x - gx, dyT = y - gy;
     const float term = sqrtf(dxT * dxT + dyT * dyT) + (tT <= p.thr ? 1.0e4f : 0.0f);
     const float cost = ((float)Sd + term) + (float)Ad;
@@ -929,6 +1149,31 @@ __global__ __launch_bounds__(64) void rollout_sampled_kernel(const SolveParams p
         part[2 + j] = acc;
     }
     if (lane == 0) { part[0] = zmax; part[1] = esum; }
+}
+
+// The slip draws of one solve, exactly the stream the sampled kernels consume: zt (K,T), zc (K,T+1), zo (T).
+__global__ void philox_slip_kernel(float *__restrict__ zt, float *__restrict__ zc, float *__restrict__ zo, uint64_t seed,
+                                   uint64_t solve, int b, int K, int T)
+{
+    const int nS = ((T + 2) & ~1) >> 1;
+    const size_t tot = (size_t)K * nS;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / nS), j = (int)(i - (size_t)k * nS);
+        float z[4];
+        philox_slip_block(seed, solve, (uint32_t)b, (uint32_t)k, (uint32_t)j, z);
+        for (int s = 0; s < 2; ++s) {
+            const int r = 2 * j + s;
+            if (r < T) zt[(size_t)k * T + r] = z[s];
+            if (r <= T) zc[(size_t)k * (T + 1) + r] = z[2 + s];
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int j = threadIdx.x; 4 * j < T; j += blockDim.x) {
+            float z[4];
+            philox_slip_block(seed, solve, (uint32_t)b, 0xffffffffu, (uint32_t)j, z);
+            for (int s = 0; s < 4; ++s)
+                if (4 * j + s < T) zo[4 * j + s] = z[s];
+        }
 }
 
 // ---- layout helpers -----------------------------------------------------------
@@ -1030,7 +1275,8 @@ size_t rollout_lds_bytes(const SolveParams &p)
 
 size_t finish_lds_bytes(const SolveParams &p)
 {
-    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + (size_t)p.nblk + kFinishThreads);
+    const size_t slip = p.slip_on ? 2 * (size_t)p.WN * p.WN + (size_t)p.T + 16 : 0;    // (mean, std) window + the draws of X*
+    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + (size_t)p.nblk + kFinishThreads + slip);
 }
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)
@@ -1057,15 +1303,22 @@ static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n 
 template <int EPS, int GEO>
 hipError_t launch_sampled_g(const SolveParams &p, hipStream_t s)
 {
-    const bool win = p.WN > 0;
-    const size_t lds = sizeof(float) * (2 * (size_t)p.WN * p.WN + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad + 64);
-    const dim3 grid(p.nblk, p.B), block(64);
-#define BN_SL(LW, SU)                                                                                                  \
-    do { hipError_t e = ensure_lds(rollout_sampled_kernel<EPS, GEO, LW, SU>, lds); if (e != hipSuccess) return e;      \
-         rollout_sampled_kernel<EPS, GEO, LW, SU><<<grid, block, lds, s>>>(p); } while (0)
-    if (win) { if (p.U) BN_SL(true, true); else BN_SL(true, false); }
-    else { if (p.U) BN_SL(false, true); else BN_SL(false, false); }
+    const dim3 grid(p.nblk, p.B);
+    const size_t lds_w = sizeof(float) * sampled_lds_floats(p.T, p.WN);
+    if (p.WN > 0 && lds_w <= 160 * 1024) {
+#define BN_SL(SU)                                                                                                      \
+    do { hipError_t e = ensure_lds(rollout_sampled_kernel<EPS, GEO, SU>, lds_w); if (e != hipSuccess) return e;        \
+         rollout_sampled_kernel<EPS, GEO, SU><<<grid, dim3(kSampledThreads), lds_w, s>>>(p); } while (0)
+        if (p.U) BN_SL(true); else BN_SL(false);
 #undef BN_SL
+    } else {
+        const size_t lds = sizeof(float) * (4 * (size_t)p.T + 2 * (size_t)p.T * kUPad + 64);
+#define BN_SL(SU)                                                                                                      \
+    do { hipError_t e = ensure_lds(rollout_sampled_global_kernel<EPS, GEO, SU>, lds); if (e != hipSuccess) return e;   \
+         rollout_sampled_global_kernel<EPS, GEO, SU><<<grid, dim3(64), lds, s>>>(p); } while (0)
+        if (p.U) BN_SL(true); else BN_SL(false);
+#undef BN_SL
+    }
     return hipGetLastError();
 }
 
@@ -1124,6 +1377,12 @@ hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K,
 hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int Kp, int T1, hipStream_t s)
 {
     gather_states_kernel<<<grid_for((size_t)n * T1 * 3), 256, 0, s>>>(X_soa, idx, out, n, Kp, T1 * 3);
+    return hipGetLastError();
+}
+
+hipError_t launch_philox_slip(float *zt, float *zc, float *zo, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s)
+{
+    philox_slip_kernel<<<grid_for((size_t)K * (T / 2 + 1)), 256, 0, s>>>(zt, zc, zo, seed, solve, b, K, T);
     return hipGetLastError();
 }
 

@@ -97,6 +97,12 @@ class NativeMPPI:
         """Injected standard normals (device pointers): transit (B,T,K), cost (B,T+1,K), optimal rollout (B,T); None = Philox."""
         _capi.check(self._lib.bn_mppi_set_slip_noise(self._h, C.c_void_p(zt_ptr), C.c_void_p(zc_ptr), C.c_void_p(zo_ptr)))
 
+    def slip_noise(self, solve_index: int, instance: int = 0):
+        """The library's Philox slip draws of a solve: zt (K,T), zc (K,T+1), zo (T)."""
+        zt = np.empty((self.K, self.T), np.float32); zc = np.empty((self.K, self.T + 1), np.float32); zo = np.empty(self.T, np.float32)
+        _capi.check(self._lib.bn_mppi_get_slip_noise(self._h, instance, solve_index, _fp(zt), _fp(zc), _fp(zo)))
+        return zt, zc, zo
+
     def set_goal(self, goal, instance: int = -1):
         _capi.check(self._lib.bn_mppi_set_goal(self._h, instance, _fp(_f32(goal, (2,)))))
 

@@ -215,6 +215,9 @@ int bn_mppi_get_costs(bn_mppi_t *h, int32_t instance, float *out_host);
 int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host);
 int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host);
 int bn_mppi_get_philox_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_index, float *out_host);
+/* Sampled-slip mode: regenerate the library's slip draws of solve `solve_index` in the oracle's layout:
+ * transit (K,T), cost (K,T+1), optimal rollout (T). */
+int bn_mppi_get_slip_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_index, float *zt_host, float *zc_host, float *zo_host);
 
 /* MPPI.get_top_samples(n), mppi.py:221-240: the n highest-weight rollouts, sorted
  * by weight descending.  states_host (n,T+1,3), weights_host (n,).  n <= K. */

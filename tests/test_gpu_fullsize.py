@@ -26,8 +26,10 @@ def _run(K, T, G, kind, seed, res=0.5):
 
 
 @pytest.mark.parametrize("K,T,G,kind", [(1024, 50, 256, "smooth"), (1024, 50, 256, "iid"), (8192, 50, 256, "smooth"),
-                                         (16384, 100, 512, "smooth"), (16384, 100, 512, "iid")],
-                         ids=["c2-smooth", "c2-iid", "c3-size", "c5-smooth", "c5-iid"])
+                                         (16384, 100, 512, "smooth"), (16384, 100, 512, "iid"),
+                                         # 2T just past a wavefront / more workgroups than columns in the last wave of the merge
+                                         (300, 33, 256, "smooth"), (320, 34, 256, "iid"), (4096, 50, 256, "smooth"), (4096, 33, 256, "smooth")],
+                         ids=["c2-smooth", "c2-iid", "c3-size", "c5-smooth", "c5-iid", "T33", "T34", "K4096", "K4096-T33"])
 def test_full_size_configs(K, T, G, kind):
     got, orc, inst = _run(K, T, G, kind, seed=11)
     assert_oracle_parity(oracle_metrics(got, orc), ctx=f"K={K} T={T} G={G} {kind}")

@@ -37,18 +37,42 @@ def _native(K, T, G, inst, sg, eps, mean, z, **kw):
         return native_outputs(pl, us, xs)
 
 
-@pytest.mark.parametrize("K,T,G,kind", [(1000, 50, 256, "smooth"), (192, 7, 64, "iid"), (8192, 50, 256, "smooth")],
-                         ids=["ragged", "small-iid", "c3"])
-def test_sampled_slip_matches_oracle_with_injected_normals(K, T, G, kind):
+@pytest.mark.parametrize("K,T,G,kind,window", [(1000, 50, 256, "smooth", True), (192, 7, 64, "iid", True), (8192, 50, 256, "smooth", True),
+                                                (64, 1, 64, "iid", True), (1000, 50, 256, "iid", False), (130, 100, 256, "smooth", True)],
+                         ids=["ragged", "small-iid", "c3", "T1", "no-window", "T100-fallback"])
+def test_sampled_slip_matches_oracle_with_injected_normals(K, T, G, kind, window):
     from oracle import oracle as O
     inst, sg, eps, mean, z = _problem(K, T, G, seed=5, kind=kind)
     p = O.make_params(K, T, G, 0.5, inst.goal.numpy(), trig=O.TRIG_SPEC)
     orc = O.solve_sampled(p, inst.risk.numpy(), sg, inst.start.numpy(), mean, eps, z["zt"], z["zc"], z["zo"])
-    got = _native(K, T, G, inst, sg, eps, mean, z)
+    got = _native(K, T, G, inst, sg, eps, mean, z, lds_window=window)
     assert_oracle_parity(oracle_metrics(got, orc), ctx=f"sampled K={K} T={T} G={G}")
     # the draws matter: the deterministic solve on the mean map gives other trajectories
     det = O.solve(p, inst.risk.numpy(), inst.start.numpy(), mean, eps)
     assert np.abs(det["X"] - orc["X"]).max() > 1e-3
+
+
+@pytest.mark.parametrize("K,T,window", [(8192, 50, True), (300, 33, True), (300, 34, False)], ids=["c3", "odd-T", "no-window"])
+def test_philox_slip_solve_matches_oracle_on_the_regenerated_draws(K, T, window):
+    """The library's own draws (Philox, in-kernel): bn_mppi_get_slip_noise regenerates them, the oracle consumes
+    them, and the solve must agree exactly as with injected draws -- control noise from the Philox stream too."""
+    from oracle import oracle as O
+    from benchnav_amd import NativeMPPI
+    G = 256
+    inst, sg, _, mean, _ = _problem(K, T, G, seed=21)
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, store_controls=True, sampled_slip=True, seed=99,
+                    lds_window=window) as pl:
+        pl.set_map(inst.risk.numpy()); pl.set_slip_std(sg); pl.set_goal(inst.goal.numpy()); pl.set_mean(mean)
+        us, xs = pl.solve(inst.start.numpy())
+        got = native_outputs(pl, us, xs)
+        n = pl.solve_count()
+        eps = pl.philox_noise(n - 1)
+        zt, zc, zo = pl.slip_noise(n - 1)
+    for z in (zt, zc):
+        assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02
+    p = O.make_params(K, T, G, 0.5, inst.goal.numpy(), trig=O.TRIG_SPEC)
+    orc = O.solve_sampled(p, inst.risk.numpy(), sg, inst.start.numpy(), mean, eps, zt, zc, zo)
+    assert_oracle_parity(oracle_metrics(got, orc), ctx=f"philox sampled K={K} T={T}")
 
 
 def test_zero_std_reduces_to_the_deterministic_planner():
