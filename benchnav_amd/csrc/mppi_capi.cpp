@@ -68,6 +68,9 @@ struct bn_mppi {
     float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
     int *d_idx = nullptr;
     float *d_slip_std = nullptr;     // sampled-slip mode
+    float *d_ustar2[2] = {nullptr, nullptr}, *d_stats2[2] = {nullptr, nullptr};   // ticket-merge outputs by solve parity
+    int *d_ticket = nullptr;
+    bool sampled_fused = false;      // one launch per solve: ticket merge + the previous tail as aux workgroup
     bool slip_std_set = false;
     // device-side closed loop (bn_mppi_env_attach / bn_mppi_episode_async)
     float *d_lat_mean = nullptr, *d_lat_std = nullptr, *d_ep_states = nullptr, *d_ep_reward = nullptr, *d_env_state = nullptr;
@@ -125,6 +128,11 @@ int flush_tail(bn_mppi *h)
     bn::SolveParams p = h->p;
     const int cur = (int)((h->solves - 1) & 1);
     p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
+    if (h->sampled_fused) {
+        p.tail_merged = 1;
+        p.ustar_prev = h->d_ustar2[cur]; p.stats_prev = h->d_stats2[cur];
+    }
+    p.tail_solve = h->solves - 1;
     if (h->in_episode) {
         p.env_on = 1;
         p.ep_index = h->ep_len - 1;
@@ -290,6 +298,14 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         BN_HIP(hipMalloc((void **)&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4));
         BN_HIP(hipMemset(h->d_slip_std, 0, (size_t)h->n_maps * p.G * p.G * 4));
         p.slip_std = h->d_slip_std;
+        for (int q = 0; q < 2; ++q) {
+            BN_HIP(hipMalloc((void **)&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4));
+            BN_HIP(hipMalloc((void **)&h->d_stats2[q], (size_t)p.B * 2 * 4));
+        }
+        BN_HIP(hipMalloc((void **)&h->d_ticket, (size_t)p.B * 4));
+        BN_HIP(hipMemset(h->d_ticket, 0, (size_t)p.B * 4));
+        p.ticket = h->d_ticket;
+        h->sampled_fused = !(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p);
     }
     BN_HIP(hipDeviceSynchronize());
     *out = h;
@@ -305,7 +321,8 @@ void bn_mppi_destroy(bn_mppi_t *h)
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1],
                     h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
                     h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
-                    h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std};
+                    h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
+                    h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -440,8 +457,9 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     // Profiling: two-launch mode brackets each kernel with events.  In the pipelined mode a solve is ONE
     // back-to-back launch of ~15 us; an event pair around every launch would add its own ~5 us of
     // dispatch latency, so events are recorded every kProfGroup launches and the mean is taken per group.
-    const bool prof_grouped = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && h->pipelined;
-    const bool prof = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && !h->pipelined;
+    const bool one_launch = h->pipelined || h->sampled_fused;
+    const bool prof_grouped = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && one_launch;
+    const bool prof = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && !one_launch;
     hipEvent_t *ev = nullptr;
     if (prof_grouped && h->prof_in_group == 0) {
         if (h->ev_used + 1 > h->ev.size()) {
@@ -487,8 +505,22 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     }
     p.have_prev = 0;
     p.mean_from_part = 0;
+    p.tail_solve = p.solve;
+    if (p.slip_on && !h->slip_std_set) return fail(BN_ERR_STATE, "bn_mppi_set_slip_std must precede solve in sampled-slip mode");
+    if (h->sampled_fused) {
+        // one launch: the rollouts, the ticket merge of this solve, and the previous solve's tail as aux workgroup
+        p.have_prev = h->tail_pending ? 1 : 0;
+        p.tail_merged = 1;
+        p.tail_solve = p.solve - 1;
+        p.ustar_cur = h->d_ustar2[cur]; p.stats_cur = h->d_stats2[cur];
+        p.ustar_prev = h->d_ustar2[prev]; p.stats_prev = h->d_stats2[prev];
+        BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
+        if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
+        h->solves += 1;
+        h->tail_pending = true;
+        return BN_OK;
+    }
     if (p.slip_on) {
-        if (!h->slip_std_set) return fail(BN_ERR_STATE, "bn_mppi_set_slip_std must precede solve in sampled-slip mode");
         BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
     } else
     BN_HIP(bn::launch_rollout(p, mode, h->stream));
@@ -791,7 +823,7 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!(h->cfg.flags & BN_FLAG_PROFILE)) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_PROFILE");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
-    if (h->pipelined) {
+    if (h->pipelined || h->sampled_fused) {
         // close the open group with one more event *before* the flush, then average complete groups only
         const int open = h->prof_in_group;
         if (h->ev_used + 1 > h->ev.size()) {

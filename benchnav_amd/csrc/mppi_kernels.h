@@ -10,6 +10,7 @@ constexpr int kRolloutsPerBlock = 64;   // lane = rollout; 64 rollouts per workg
 constexpr int kRolloutThreads = 320;    // 5 wavefronts per workgroup, specialised by role (chain / 2 producers / 2 consumers)
 constexpr int kChunk = 4;                // time steps per barrier phase of the rollout kernel
 constexpr int kUPad = 65;               // LDS row pitch of the control tile (bank-conflict-free both ways)
+constexpr int kWideFinishThreads = 1024;           // stand-alone tail of the sizes that are not pipelined (K > 2048)
 constexpr int kFinishThreads = kRolloutThreads;   // the tail runs as a stand-alone kernel or as the aux workgroup of a rollout launch
 
 enum EpsMode : int { kEpsPhilox = 0, kEpsKT2 = 1, kEpsT2K = 2 };
@@ -65,6 +66,13 @@ struct SolveParams {
     int slip_on;         // every traversability lookup draws slip ~ Normal(map, slip_std)[cell]
     const float *slip_std;             // (n_maps, G, G)
     const float *zt, *zc, *zo;         // injected standard normals: transit (B,T,K), cost (B,T+1,K), X* (B,T); or nullptr: Philox
+    // fused tail of the sampled kernel: the last workgroup of an instance to finish (ticket) merges the partials itself;
+    // weights / X* of that solve are written by the aux workgroup of the NEXT launch, or by the stand-alone tail
+    int *ticket;                       // (B,) workgroups of this launch done so far; reset by the last one
+    float *ustar_cur, *stats_cur;      // (B, T, 2), (B, 2): merge outputs of this solve (double-buffered by solve parity)
+    const float *ustar_prev, *stats_prev;   // merge outputs of the solve whose tail this launch / the stand-alone tail writes
+    int tail_merged;                   // the tail reads (ustar_prev, stats_prev) instead of merging `part`
+    uint64_t tail_solve;               // index of the solve whose tail is written (its X* draws)
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)
@@ -78,6 +86,7 @@ size_t finish_lds_bytes(const SolveParams &p);
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s);
+bool sampled_fused(const SolveParams &p);   // the sampled launch merges by ticket and carries the previous tail (LDS-window variant)
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
                       float *w, int *best, hipStream_t s);
 

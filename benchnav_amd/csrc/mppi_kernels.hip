@@ -39,8 +39,13 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
         if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                          \
             p.stamps[slot] = __builtin_readcyclecounter();                                               \
     } while (0)
+#define BN_STAMP_ANY(slot)                                                                               \
+    do {                                                                                                 \
+        if (p.stamps && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define BN_STAMP(slot) do { } while (0)
+#define BN_STAMP_ANY(slot) do { } while (0)
 #endif
 
 // Geometry specialisations of the cell index ((p - origin) / res).floor().int()  (grid_map.py:195-209):
@@ -270,16 +275,22 @@ __device__ __forceinline__ float wave_sum(float v)
 // Softmin merge and the tail of a solve (shared by the finish kernel, the aux block of the
 // pipelined rollout kernel, and the rollout blocks' own prologue merge).
 // ------------------------------------------------------------------------------
+template <int NT>
 __device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool is_max)
 {
     v = is_max ? wave_max(v) : wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
     float r = red[0];
-    for (int i = 1; i < kFinishThreads / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    for (int i = 1; i < NT / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
     __syncthreads();
     return r;
 }
+
+// Device-scope accesses that bypass the per-XCD L2 (sc1): what lets workgroups on different XCDs exchange their
+// partials inside one launch without a full L2 write-back / invalidate (see ticket_merge).
+__device__ __forceinline__ void store_agent(float *ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_agent(const float *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Merge the nblk per-block statistics (max z, sum e, sum e*u) of one instance into
 //   U*[j] = sum_k w_k u_k[j]      mppi.py:193-199
@@ -305,9 +316,11 @@ __device__ __forceinline__ MergeLoads merge_issue(const float *__restrict__ part
     return L;
 }
 
+template <int NT, bool AGENT = false>
 __device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
                                                float *red, int tid, float &m_out, float &S_out, const MergeLoads *pre)
 {
+#define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
     const int PS = 2 + 2 * T;
     const int lane = tid & 63;
     float m, S;
@@ -323,47 +336,117 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         // loop below, and a ds_bpermute shuffle returns nothing from the lanes that did not
         const int fb = __float_as_int(f);
 #define BN_SCALE(i) __int_as_float(__builtin_amdgcn_readlane(fb, (i)))
-        for (int jj = tid; jj < 2 * T; jj += kFinishThreads) {
+        for (int jj = tid; jj < 2 * T; jj += NT) {
             float acc = 0.0f;
             if (jj == L.j) {
 #pragma unroll
                 for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], BN_SCALE(i), acc);   // f == 0 past nblk
-                for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], BN_SCALE(i), acc);
+                for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), BN_SCALE(i), acc);
             } else {
-                for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], BN_SCALE(i), acc);
+                for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), BN_SCALE(i), acc);
             }
             us[jj] = acc / S;
         }
 #undef BN_SCALE
-    } else {
+    } else if constexpr (NT < 512) {
         float mm = -INFINITY;
-        for (int i = tid; i < nblk; i += kFinishThreads) mm = fmaxf(mm, part[(size_t)i * PS]);
-        m = block_reduce(mm, red, tid, true);
+        for (int i = tid; i < nblk; i += NT) mm = fmaxf(mm, BN_PLD((size_t)i * PS));
+        m = block_reduce<NT>(mm, red, tid, true);
         float s = 0.0f;
-        for (int i = tid; i < nblk; i += kFinishThreads) {
-            const float f = expf(part[(size_t)i * PS] - m);
+        for (int i = tid; i < nblk; i += NT) {
+            const float f = expf(BN_PLD((size_t)i * PS) - m);
             sc[i] = f;
-            s += part[(size_t)i * PS + 1] * f;
+            s += BN_PLD((size_t)i * PS + 1) * f;
         }
-        S = block_reduce(s, red, tid, false);            // the barrier inside also publishes sc[]
-        for (int jj = tid; jj < 2 * T; jj += kFinishThreads) {
+        S = block_reduce<NT>(s, red, tid, false);        // the barrier inside also publishes sc[]
+        for (int jj = tid; jj < 2 * T; jj += NT) {
             float acc = 0.0f;
-            for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(part[(size_t)i * PS + 2 + jj], sc[i], acc);
+            for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), sc[i], acc);
             us[jj] = acc / S;
+        }
+    } else {
+        // Many blocks (the stand-alone tail of a large-K solve, NT = 1024; the ticket merge of the sampled kernel, 512): the part rows are split over the
+        // waves (row i -> wave i mod NW) and every load a thread needs -- its block's (max, sum) pair and the
+        // first kPreRows x kPreCols of its tile -- is issued before the first reduction: one memory round trip.
+        constexpr int NW = NT / 64, kPreRows = NT >= 1024 ? 8 : 16, kPreCols = 2;     // covers nblk <= 128 (K = 8192) at T <= 64
+        const int wv = tid >> 6;
+        float *accw = red + 32;                          // NW x 2T per-wave partial sums
+        const bool has = tid < nblk;
+        const float mi = has ? BN_PLD((size_t)tid * PS) : -INFINITY;
+        const float si = has ? BN_PLD((size_t)tid * PS + 1) : 0.0f;
+        float pre[kPreRows][kPreCols];
+#pragma unroll
+        for (int r = 0; r < kPreRows; ++r)
+#pragma unroll
+            for (int c = 0; c < kPreCols; ++c) {
+                const int i = wv + NW * r, jj = lane + 64 * c;
+                pre[r][c] = (i < nblk && jj < 2 * T) ? BN_PLD((size_t)i * PS + 2 + jj) : 0.0f;
+            }
+        float mm = mi;
+        for (int i = tid + NT; i < nblk; i += NT) mm = fmaxf(mm, BN_PLD((size_t)i * PS));
+        m = block_reduce<NT>(mm, red, tid, true);
+        float s = 0.0f;
+        if (has) {
+            const float f = expf(mi - m);
+            sc[tid] = f;
+            s = si * f;
+        }
+        for (int i = tid + NT; i < nblk; i += NT) {
+            const float f = expf(BN_PLD((size_t)i * PS) - m);
+            sc[i] = f;
+            s += BN_PLD((size_t)i * PS + 1) * f;
+        }
+        S = block_reduce<NT>(s, red, tid, false);        // the barrier inside also publishes sc[]
+        float acc[kPreCols] = {};
+#pragma unroll
+        for (int r = 0; r < kPreRows; ++r) {
+            const int i = wv + NW * r;
+            if (i < nblk) {
+                const float f = sc[i];
+#pragma unroll
+                for (int c = 0; c < kPreCols; ++c) acc[c] = __builtin_fmaf(pre[r][c], f, acc[c]);
+            }
+        }
+#pragma unroll 4
+        for (int i = wv + NW * kPreRows; i < nblk; i += NW) {
+            const float f = sc[i];
+#pragma unroll
+            for (int c = 0; c < kPreCols; ++c) {
+                const int jj = lane + 64 * c;
+                acc[c] = __builtin_fmaf(jj < 2 * T ? BN_PLD((size_t)i * PS + 2 + jj) : 0.0f, f, acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kPreCols; ++c)
+            if (lane + 64 * c < 2 * T) accw[wv * 2 * T + lane + 64 * c] = acc[c];
+        for (int jj = lane + 64 * kPreCols; jj < 2 * T; jj += 64) {       // columns past the prefetched ones (T > 64)
+            float a = 0.0f;
+            for (int i = wv; i < nblk; i += NW) a = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), sc[i], a);
+            accw[wv * 2 * T + jj] = a;
+        }
+        __syncthreads();
+        for (int jj = tid; jj < 2 * T; jj += NT) {
+            float a = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += accw[w * 2 * T + jj];
+            us[jj] = a / S;
         }
     }
     __syncthreads();
     m_out = m;
     S_out = S;
+#undef BN_PLD
 }
 
 // The tail of one solve of instance b: U* (and the next mean), softmin statistics, normalised weights,
-// a stable copy of the costs, and the batch-1 rollout X* of U*.  256 threads.
-// LDS: [ window | ustar 2T | scale nblk | red 4 ]
-template <int GEO, bool LDSWIN>
+// a stable copy of the costs, and the batch-1 rollout X* of U*.  NT threads (320 as the aux workgroup, 1024 stand-alone for large K).
+// LDS: [ window | ustar 2T | scale nblk | red 32 | per-wave sums NT/64 x 2T | sampled mode: draws, (mean, std) window ]
+template <int GEO, bool LDSWIN, int NT>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
 {
+    // p.tail_merged: U* and the softmin statistics of this solve were merged already (ticket merge of the sampled
+    // kernel, which also wrote the next mean); they come from (ustar_prev, stats_prev).
     const int T = p.T, K = p.K, nblk = p.nblk, PS = 2 + 2 * p.T;
     float *win = smem;
     float *us = win + (LDSWIN ? p.WN * p.WN : 0);
@@ -379,15 +462,26 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN && !p.slip_on) {
         w = window_origin<GEO>(p, sx, sy);
-        stage_window(win, map, w, p.WN, p.G, tid, kFinishThreads);
+        stage_window(win, map, w, p.WN, p.G, tid, NT);
     }
     BN_STAMP(9);
 
     float m, S;
-    merge_partials(part, nblk, T, us, sc, red, tid, m, S, nullptr);
-    for (int j = tid; j < 2 * T; j += kFinishThreads) {
-        p.ustar[(size_t)b * 2 * T + j] = us[j];
-        p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
+    if (p.tail_merged) {
+        for (int j = tid; j < 2 * T; j += NT) {
+            const float u = p.ustar_prev[(size_t)b * 2 * T + j];
+            us[j] = u;
+            p.ustar[(size_t)b * 2 * T + j] = u;
+        }
+        m = p.stats_prev[b * 2 + 0];
+        S = p.stats_prev[b * 2 + 1];
+        __syncthreads();
+    } else {
+        merge_partials<NT>(part, nblk, T, us, sc, red, tid, m, S, nullptr);
+        for (int j = tid; j < 2 * T; j += NT) {
+            p.ustar[(size_t)b * 2 * T + j] = us[j];
+            p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
+        }
     }
     if (tid == 0) {
         p.stats[b * 2 + 0] = m;
@@ -415,22 +509,23 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         // sampled-slip mode: the optimal rollout draws a fresh slip per transit as well (mppi.py:202-214 with
         // traversability_model.py:65-69).  Draws and the (mean, std) window are staged by all threads first.
         const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
-        float *zol = red + kFinishThreads;                       // T + 4 draws
+        float *zol = red + 32 + (NT / 64) * 2 * T;                      // T + 4 draws
         float2 *win2 = reinterpret_cast<float2 *>((reinterpret_cast<uintptr_t>(zol + ((T + 7) & ~3)) + 7) & ~(uintptr_t)7);
         if (p.zo) {
-            for (int t = tid; t < T; t += kFinishThreads) zol[t] = p.zo[(size_t)b * T + t];
+            for (int t = tid; t < T; t += NT) zol[t] = p.zo[(size_t)b * T + t];
         } else {
-            for (int j = tid; 4 * j < T; j += kFinishThreads) philox_slip_block(p.seed, p.solve, (uint32_t)b, 0xffffffffu, (uint32_t)j, zol + 4 * j);
+            for (int j = tid; 4 * j < T; j += NT) philox_slip_block(p.seed, p.tail_solve, (uint32_t)b, 0xffffffffu, (uint32_t)j, zol + 4 * j);
         }
         if (LDSWIN) {
             w = window_origin<GEO>(p, sx, sy);
-            for (int e = tid; e < p.WN * p.WN; e += kFinishThreads) {
+            for (int e = tid; e < p.WN * p.WN; e += NT) {
                 const int r = e / p.WN, c = e - r * p.WN;
                 const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
                 win2[e] = make_float2(map[g], sg[g]);
             }
         }
         __syncthreads();
+        BN_STAMP(12);
         if (tid == 0) {
             float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
             float xn, yn, tn;
@@ -439,12 +534,25 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
                 c.x = sx; c.y = sy; c.th = sth;
                 sincos_spec(c.th, c.sn, c.cs);
                 c.e = slip_cell_safe<GEO, true>(p, w, sx, sy);
-                for (int t = 0; t < T; ++t) {
-                    if (t == 0) slip_chain_step<GEO, true>(p, win2, w, c, us[0], us[1], zol[0], xn, yn, tn);
-                    else slip_chain_step<GEO, false>(p, win2, w, c, us[2 * t], us[2 * t + 1], zol[t], xn, yn, tn);
+                slip_chain_step<GEO, true>(p, win2, w, c, us[0], us[1], zol[0], xn, yn, tn);
+                Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
+                int t = 1;
+                for (; t + 4 <= T; t += 4) {                 // controls and draws of four steps read up front
+                    float uq[4][3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; uq[i][2] = zol[t + i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        slip_chain_step<GEO, false>(p, win2, w, c, uq[i][0], uq[i][1], uq[i][2], xn, yn, tn);
+                        Xs[3 * (t + i)] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
+                    }
+                }
+                for (; t < T; ++t) {
+                    slip_chain_step<GEO, false>(p, win2, w, c, us[2 * t], us[2 * t + 1], zol[t], xn, yn, tn);
                     Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
                 }
                 Xs[3 * T] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
+                BN_STAMP(11);
             } else {
                 float x = sx, y = sy, th = sth;
                 for (int t = 0; t < T; ++t) {
@@ -495,7 +603,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         const float *cost = cost_all + (size_t)b * K;
         float *wout = p.w + (size_t)b * K;
         float *cout = p.cost_out + (size_t)b * K;
-        for (int k = tid - 64; k < K; k += kFinishThreads - 64) {
+        for (int k = tid - 64; k < K; k += NT - 64) {
             const float ck = cost[k];
             cout[k] = ck;
             wout[k] = expf((-ck) / p.lambda_ - m) / S;
@@ -564,7 +672,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     if (blockIdx.x == p.nblk) {
         // pipelined mode: the extra workgroup computes the tail of the PREVIOUS solve (U*, X*, weights)
         // while the other workgroups roll out this one
-        finish_body<GEO, LDSWIN>(p, blockIdx.y, p.part_prev, p.cost_prev, p.state_prev, smem);
+        finish_body<GEO, LDSWIN, kRolloutThreads>(p, blockIdx.y, p.part_prev, p.cost_prev, p.state_prev, smem);
         return;
     }
     const int T = p.T, K = p.K;
@@ -610,7 +718,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     }
     if (p.mean_from_part) {
         float m_unused, S_unused;
-        merge_partials(part_prev, p.nblk, T, ml, ring, ring + p.nblk, tid, m_unused, S_unused, pre_ok ? &pre : nullptr);
+        merge_partials<kRolloutThreads>(part_prev, p.nblk, T, ml, ring, ring + p.nblk, tid, m_unused, S_unused, pre_ok ? &pre : nullptr);
         for (int j = tid; j < 2 * T; j += kRolloutThreads) mv[j] = ml[j] * ((j & 1) ? p.iv1 : p.iv0);
     } else {
         for (int j = tid; j < 2 * T; j += kRolloutThreads) {
@@ -816,11 +924,11 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
 // Finish kernel.  grid = B, block = 256: finish_body for the latest solve (also the flush of the
 // pipelined mode).
 // ------------------------------------------------------------------------------
-template <int GEO, bool LDSWIN>
-__global__ __launch_bounds__(kFinishThreads) void finish_kernel(const SolveParams p)
+template <int GEO, bool LDSWIN, int NT>
+__global__ __launch_bounds__(NT) void finish_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    finish_body<GEO, LDSWIN>(p, blockIdx.x, p.part, p.cost, p.state, smem);
+    finish_body<GEO, LDSWIN, NT>(p, blockIdx.x, p.part, p.cost, p.state, smem);
 }
 
 // ------------------------------------------------------------------------------
@@ -919,6 +1027,37 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
 // LDS: [ slot rows (T+1) x 64 float4 | window WN^2 float2 | Zt TP x 64 | Zc TP x 64 | controls 2T x 65 | mean 2T |
 //        mean*inv_var 2T | e 64 | control cost 64 ],  TP = T+1 rounded up to even.
 // ------------------------------------------------------------------------------
+// Ticket merge: every workgroup of instance b publishes its partials, takes a ticket, and the one that draws the
+// last ticket merges all of them (fixed block order: the result does not depend on which workgroup that is) into
+// U* = the next mean, plus the softmin statistics the tail needs for the weights.  Saves the merge launch.
+// LDS scratch: [ us 2T | sc nblk | red 32 | per-wave sums (NT/64) x 2T | flag ].
+template <int NT>
+__device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, float *scratch)
+{
+    const int T = p.T, tid = threadIdx.x;
+    float *us = scratch, *sc = us + 2 * T, *red = sc + p.nblk;
+    int *flag = reinterpret_cast<int *>(red + 32 + (NT / 64) * 2 * T);
+    // The partials were stored with store_agent (write-through to the device coherence point); once every wave has
+    // seen them acknowledged (vmcnt 0) and the workgroup has met at the barrier, the ticket is taken.  The last
+    // workgroup reads all partials with load_agent.  No __threadfence: that would write back / invalidate the
+    // whole L2 once per workgroup (measured: +18 us per launch at 128 workgroups).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *flag = (atomicAdd(p.ticket + b, 1) == p.nblk - 1) ? 1 : 0;
+    __syncthreads();
+    if (!*flag) return;
+    BN_STAMP_ANY(6);
+    if (tid == 0) p.ticket[b] = 0;                     // ready for the next launch (ordered by the stream)
+    float m, S;
+    merge_partials<NT, true>(p.part + (size_t)b * p.nblk * (2 + 2 * T), p.nblk, T, us, sc, red, tid, m, S, nullptr);
+    for (int j = tid; j < 2 * T; j += NT) {
+        p.ustar_cur[(size_t)b * 2 * T + j] = us[j];
+        p.mean[(size_t)b * 2 * T + j] = us[j];         // _previous_action_seq = U*, no shift (mppi.py:217)
+    }
+    if (tid == 0) { p.stats_cur[b * 2 + 0] = m; p.stats_cur[b * 2 + 1] = S; }
+    BN_STAMP_ANY(7);
+}
+
 constexpr int kSampledWaves = 8;
 constexpr int kSampledThreads = 64 * kSampledWaves;
 
@@ -939,6 +1078,11 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
     float *Zt = reinterpret_cast<float *>(win2 + WN2), *Zc = Zt + 64 * TP;
     float *Ul = Zc + 64 * TP, *ml = Ul + 2 * T * kUPad, *mv = ml + 2 * T, *el = mv + 2 * T, *ad = el + 64;
     const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
+    if (blockIdx.x == p.nblk) {
+        // aux workgroup: weights, cost copy and X* of the previous solve (merged by its own last workgroup)
+        finish_body<GEO, true, kSampledThreads>(p, b, nullptr, p.cost_prev, p.state_prev, smem);
+        return;
+    }
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = blockIdx.x * 64 + lane;
     const bool active = k < K;
@@ -952,6 +1096,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
     float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
     float *Ub = STORE_U ? p.U + (size_t)b * T * 2 * Kp + k : nullptr;
 
+    BN_STAMP(0);
     // ---- phase 0: window of (mean, std) pairs, warm-start mean ----
     for (int e = tid; e < WN2; e += kSampledThreads) {
         const int r = e / p.WN, c = e - r * p.WN;
@@ -989,6 +1134,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         }
     }
     __syncthreads();
+    BN_STAMP(1);
 
     // ---- phase 2: the chain (wave 0) and the control cost (wave 1) ----
     if (wid == 0) {
@@ -1027,6 +1173,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         ad[lane] = (float)Ad;
     }
     __syncthreads();
+    BN_STAMP(2);
 
     // ---- phase 3: slot rows -> trajectory stores and sampled stage / terminal cost ----
     for (int t = wid; t <= T; t += kSampledWaves) {
@@ -1039,6 +1186,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         Zc[t * 64 + lane] = sqrtf(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f);  // objectives.py:46-53
     }
     __syncthreads();
+    BN_STAMP(3);
 
     // ---- phase 4: rollout cost and the workgroup's softmin statistics ----
     if (wid == 0) {
@@ -1053,7 +1201,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         el[lane] = e;
         if (lane == 0) {
             float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
-            part[0] = zmax; part[1] = esum;
+            store_agent(part, zmax); store_agent(part + 1, esum);
         }
     }
     __syncthreads();
@@ -1063,8 +1211,10 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         float acc = 0.0f;
 #pragma unroll 16
         for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
-        part[2 + j] = acc;
+        store_agent(part + 2 + j, acc);
     }
+    BN_STAMP(5);
+    ticket_merge<kSampledThreads>(p, b, smem);          // the slot rows are dead: their LDS is the merge scratch
 }
 
 // The same solve without the LDS window (BN_FLAG_NO_LDS_WINDOW, or a window/horizon too large for the LDS):
@@ -1260,13 +1410,27 @@ template <int GEO, bool LDSWIN>
 hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
 {
     const size_t lds = finish_lds_bytes(p);
-    hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN>, lds);
-    if (e != hipSuccess) return e;
-    finish_kernel<GEO, LDSWIN><<<dim3(p.B), dim3(kFinishThreads), lds, s>>>(p);
+    if (p.nblk > 32) {                    // sizes the pipelined mode does not take: a wide tail (merge tiles, weights)
+        hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN, kWideFinishThreads>, lds);
+        if (e != hipSuccess) return e;
+        finish_kernel<GEO, LDSWIN, kWideFinishThreads><<<dim3(p.B), dim3(kWideFinishThreads), lds, s>>>(p);
+    } else {
+        hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN, kFinishThreads>, lds);
+        if (e != hipSuccess) return e;
+        finish_kernel<GEO, LDSWIN, kFinishThreads><<<dim3(p.B), dim3(kFinishThreads), lds, s>>>(p);
+    }
     return hipGetLastError();
 }
 
 }  // namespace
+
+bool sampled_fused(const SolveParams &p)
+{
+    // the multi-wave kernel needs the LDS window and room for its tiles; its LDS also holds the aux tail / merge scratch
+    const size_t need = sizeof(float) * sampled_lds_floats(p.T, p.WN);
+    const size_t tail = finish_lds_bytes(p) + sizeof(float) * (8 * 2 * (size_t)p.T + 64);
+    return p.slip_on && p.WN > 0 && need <= 160 * 1024 && tail <= need;
+}
 
 size_t rollout_lds_bytes(const SolveParams &p)
 {
@@ -1276,7 +1440,8 @@ size_t rollout_lds_bytes(const SolveParams &p)
 size_t finish_lds_bytes(const SolveParams &p)
 {
     const size_t slip = p.slip_on ? 2 * (size_t)p.WN * p.WN + (size_t)p.T + 16 : 0;    // (mean, std) window + the draws of X*
-    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + (size_t)p.nblk + kFinishThreads + slip);
+    const size_t waves = (p.nblk > 32 ? kWideFinishThreads : kFinishThreads) / 64;       // per-wave partial sums of the wide merge
+    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + (size_t)p.nblk + 32 + waves * 2 * (size_t)p.T + slip);
 }
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)
@@ -1303,9 +1468,9 @@ static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n 
 template <int EPS, int GEO>
 hipError_t launch_sampled_g(const SolveParams &p, hipStream_t s)
 {
-    const dim3 grid(p.nblk, p.B);
     const size_t lds_w = sizeof(float) * sampled_lds_floats(p.T, p.WN);
-    if (p.WN > 0 && lds_w <= 160 * 1024) {
+    const dim3 grid(p.nblk + (sampled_fused(p) && p.have_prev ? 1 : 0), p.B);
+    if (sampled_fused(p)) {
 #define BN_SL(SU)                                                                                                      \
     do { hipError_t e = ensure_lds(rollout_sampled_kernel<EPS, GEO, SU>, lds_w); if (e != hipSuccess) return e;        \
          rollout_sampled_kernel<EPS, GEO, SU><<<grid, dim3(kSampledThreads), lds_w, s>>>(p); } while (0)
