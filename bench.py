@@ -73,6 +73,8 @@ def timed_solves(pl, state_dev, eps_ring, kind, steps, sync):
     else:                                            # eps_ring: one contiguous tensor (ring, ...), cycled per solve
         pl.solve_n_async_device(steps, state_dev.data_ptr(), eps_ring.data_ptr(), kind, eps_ring.shape[0],
                                 eps_ring[0].numel())
+    if os.environ.get("BENCH_DEBUG") and steps >= 1000:
+        print(f"[timed] enqueue of {steps} launches returned after {(time.perf_counter() - t0) / steps * 1e6:.2f} us/launch", file=sys.stderr)
     pl.flush()
     sync()
     return time.perf_counter() - t0
@@ -88,6 +90,8 @@ def settle(make, state_dev, eps_ring, kind, warmup, sync_local, tries=3):
         timed_solves(pl, state_dev, eps_ring, kind, max(warmup, 1), sync_local)
         probes = [timed_solves(pl, state_dev, eps_ring, kind, 100, sync_local) / 100 for _ in range(3)]
         p = min(probes)
+        if os.environ.get("BENCH_DEBUG"):
+            print(f"[settle] probes us/step: {[round(x * 1e6, 2) for x in probes]}", file=sys.stderr)
         best = p if best is None else min(best, p)
         if p <= 5 * best and p < 2e-3:
             return pl
@@ -103,7 +107,7 @@ def cpu_baseline(inst, seconds):
     pb = TP.Problem(risk=inst.risk, goal=inst.goal, grid_size=G, resolution=RES, x_limits=(0.0, G * RES),
                     y_limits=(0.0, G * RES), sigmas=torch.tensor([0.5, 0.5]), lambda_=0.5, stuck_threshold=0.3,
                     u_min=torch.tensor([0.0, -1.0]), u_max=torch.tensor([1.0, 1.0]))
-    default_threads = torch.get_num_threads()
+    default_threads = HOST_THREADS
     runs = {}
     for threads in sorted({1, default_threads}):
         torch.set_num_threads(threads)
@@ -144,8 +148,14 @@ def cpu_baseline(inst, seconds):
     return out
 
 
+HOST_THREADS = torch.get_num_threads()
+
+
 def main():
     a = parse()
+    # The GPU legs need no host arithmetic: keep torch's intra-op pool out of the process until the CPU baseline leg
+    # (spinning pool threads next to the HIP runtime's submission thread were seen to stretch a timed loop 2x).
+    torch.set_num_threads(1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

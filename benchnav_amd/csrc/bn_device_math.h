@@ -87,12 +87,21 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi)
 // ---- Philox4x32-10 + Box-Muller ------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
 
+__device__ __forceinline__ uint64_t mul_wide_u32(uint32_t a, uint32_t b)
+{
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "vcc");
+    return r;
+}
+
 __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        // one v_mad_u64_u32 per product (both halves; measured full rate, tools/ubench3.hip) instead of
+        // v_mul_lo_u32 + v_mul_hi_u32 (each ~4.5 SIMD cycles per wavefront)
+        const uint64_t p0 = mul_wide_u32(0xD2511F53u, c.x), p1 = mul_wide_u32(0xCD9E8D57u, c.z);
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
