@@ -54,6 +54,10 @@ SYMBOLS = {
     "bn_mppi_solve": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, _FP, _FP]),
     "bn_mppi_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_solve_n_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64]),
+    "bn_mppi_set_rollout_offset": (C.c_int, [_H, C.c_int64]),
+    "bn_mppi_shard_rollout_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "bn_mppi_shard_partials": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "bn_mppi_shard_finish_async": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "bn_mppi_env_attach": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint64]),
     "bn_mppi_episode_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_void_p]),
     "bn_mppi_episode_log": (C.c_int, [_H, _FP, _FP, _FP, C.POINTER(C.c_int32)]),

@@ -70,6 +70,7 @@ struct bn_mppi {
     float *d_slip_std = nullptr;     // sampled-slip mode
     float *d_ustar2[2] = {nullptr, nullptr}, *d_stats2[2] = {nullptr, nullptr};   // ticket-merge outputs by solve parity
     int *d_ticket = nullptr;
+    bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
     bool sampled_fused = false;      // one launch per solve: ticket merge + the previous tail as aux workgroup
     bool slip_std_set = false;
     // device-side closed loop (bn_mppi_env_attach / bn_mppi_episode_async)
@@ -412,8 +413,9 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
     return BN_OK;
 }
 
-int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
-                        bn_noise_kind noise)
+// shard_rollout: the rollouts of a K-sharded solve only (bn_mppi_shard_rollout_async); the tail follows the exchange.
+static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise,
+                      bool shard_rollout)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!states) return fail(BN_ERR_INVALID, "states is null");
@@ -457,7 +459,13 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     // Profiling: two-launch mode brackets each kernel with events.  In the pipelined mode a solve is ONE
     // back-to-back launch of ~15 us; an event pair around every launch would add its own ~5 us of
     // dispatch latency, so events are recorded every kProfGroup launches and the mean is taken per group.
-    const bool one_launch = h->pipelined || h->sampled_fused;
+    if (shard_rollout) {
+        if (int rc = flush_tail(h)) return rc;
+        if (h->shard_pending) return fail(BN_ERR_STATE, "the previous sharded solve still waits for bn_mppi_shard_finish_async");
+    } else if (h->shard_pending) {
+        return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
+    }
+    const bool one_launch = !shard_rollout && (h->pipelined || h->sampled_fused);
     const bool prof_grouped = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && one_launch;
     const bool prof = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && !one_launch;
     hipEvent_t *ev = nullptr;
@@ -485,7 +493,7 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     p.solve = h->solves;
     p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state_copy = h->d_state_copy[cur];
     p.part_prev = h->d_part[prev]; p.cost_prev = h->d_cost[prev]; p.state_prev = h->d_state_copy[prev];
-    if (h->pipelined) {
+    if (h->pipelined && !shard_rollout) {
         // one launch: merge + tail of the previous solve ride along with this solve's rollouts
         p.have_prev = h->tail_pending ? 1 : 0;
         p.mean_from_part = h->tail_pending ? 1 : 0;
@@ -507,7 +515,7 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     p.mean_from_part = 0;
     p.tail_solve = p.solve;
     if (p.slip_on && !h->slip_std_set) return fail(BN_ERR_STATE, "bn_mppi_set_slip_std must precede solve in sampled-slip mode");
-    if (h->sampled_fused) {
+    if (h->sampled_fused && !shard_rollout) {
         // one launch: the rollouts, the ticket merge of this solve, and the previous solve's tail as aux workgroup
         p.have_prev = h->tail_pending ? 1 : 0;
         p.tail_merged = 1;
@@ -525,11 +533,69 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     } else
     BN_HIP(bn::launch_rollout(p, mode, h->stream));
     if (prof) BN_HIP(hipEventRecord(ev[1], h->stream));
+    if (shard_rollout) {
+        if (prof) BN_HIP(hipEventRecord(ev[2], h->stream));
+        h->solves += 1;
+        h->tail_pending = false;
+        h->shard_pending = true;
+        return BN_OK;
+    }
     p.state = p.state_copy;
     BN_HIP(bn::launch_finish(p, h->stream));
     if (prof) BN_HIP(hipEventRecord(ev[2], h->stream));
     h->solves += 1;
     h->tail_pending = false;
+    return BN_OK;
+}
+
+int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
+                        bn_noise_kind noise)
+{
+    return solve_impl(h, states, states_where, eps, noise, false);
+}
+
+int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (first_rollout < 0 || first_rollout + h->p.K > 0x7fffffffLL) return fail(BN_ERR_INVALID, "first_rollout out of range");
+    if (int rc = flush_tail(h)) return rc;
+    h->p.k0 = (int)first_rollout;
+    return BN_OK;
+}
+
+int bn_mppi_shard_rollout_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
+                                bn_noise_kind noise)
+{
+    if (h && h->p.B != 1) return fail(BN_ERR_INVALID, "a K-sharded solve takes one instance per handle");
+    if (h && h->p.slip_on) return fail(BN_ERR_INVALID, "K-sharding is not available in sampled-slip mode");
+    return solve_impl(h, states, states_where, eps, noise, true);
+}
+
+int bn_mppi_shard_partials(bn_mppi_t *h, const float **partials_device, int32_t *workgroups, int32_t *floats_per_workgroup)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!h->shard_pending) return fail(BN_ERR_STATE, "no sharded solve in flight");
+    const int cur = (int)((h->solves - 1) & 1);
+    if (partials_device) *partials_device = h->d_part[cur];
+    if (workgroups) *workgroups = h->p.nblk;
+    if (floats_per_workgroup) *floats_per_workgroup = 2 + 2 * h->p.T;
+    return BN_OK;
+}
+
+int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, int32_t total_workgroups)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!h->shard_pending) return fail(BN_ERR_STATE, "no sharded solve in flight");
+    if (!all_partials_device || total_workgroups < h->p.nblk) return fail(BN_ERR_INVALID, "need the partials of every shard");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    bn::SolveParams p = h->p;
+    const int cur = (int)((h->solves - 1) & 1);
+    p.solve = p.tail_solve = h->solves - 1;
+    p.part = const_cast<float *>(all_partials_device);      // merged in shard order: identical on every rank
+    p.nblk = total_workgroups;
+    p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
+    BN_HIP(bn::launch_finish(p, h->stream));                 // weights of the local rollouts, normalised by the global sum
+    h->shard_pending = false;
     return BN_OK;
 }
 
@@ -747,7 +813,7 @@ int bn_mppi_get_philox_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_inde
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
     const size_t n = (size_t)h->p.K * h->p.T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
-    BN_HIP(bn::launch_philox_noise(h->d_scratch, h->p.seed, solve_index, instance, h->p.K, h->p.T, h->stream));
+    BN_HIP(bn::launch_philox_noise(h->d_scratch, h->p.seed, solve_index, instance, h->p.K, h->p.T, h->p.k0, h->stream));
     BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
     return BN_OK;
@@ -885,6 +951,7 @@ int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise)
 }
 
 #ifdef BN_TIMING
+int bn_mppi_debug_blocks_per_cu(bn_mppi_t *h) { return bn::rollout_blocks_per_cu(h->p); }
 /* tools/ablate.py only: device buffer of >= 16 uint64 for the in-kernel cycle stamps */
 void bn_mppi_debug_set_stamps(bn_mppi_t *h, void *device_ptr) { h->p.stamps = (unsigned long long *)device_ptr; }
 #endif

@@ -25,6 +25,7 @@ struct SolveParams {
     int map_stride;      // G*G if every instance has its own map, 0 if shared
     int pow2;            // resolution is a power of two
     int store_u;
+    int k0;              // global index of this handle's rollout 0 (K-sharded solve: rank r owns rollouts [k0, k0 + K)); keys the Philox stream
     float res, inv_res;
     float x0, y0;        // index origin == lower clamp (reference grid_map.py:199-201, robot_model.py:93-94)
     float x_hi, y_hi;    // upper clamp
@@ -82,6 +83,7 @@ struct SolveParams {
 
 size_t rollout_lds_bytes(const SolveParams &p);
 size_t finish_lds_bytes(const SolveParams &p);
+int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer for the headline rollout kernel (diagnostics)
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
@@ -95,6 +97,6 @@ hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, i
 hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int Kp, int T, hipStream_t s);  // (T,2,Kp)->(K,T,2)
 hipError_t launch_gather_states(const float *X_soa, const int *idx, float *out, int n, int Kp, int T1, hipStream_t s);
 hipError_t launch_philox_slip(float *zt, float *zc, float *zo, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s);   // (K,T), (K,T+1), (T)
-hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s);
+hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, int k0, hipStream_t s);
 
 }  // namespace bn

@@ -43,9 +43,22 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
     do {                                                                                                 \
         if (p.stamps && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_readcyclecounter(); \
     } while (0)
+// per-workgroup trace (tools/block_trace.py): wall clock (100 MHz, chip-wide) at entry and exit, cycles, HW_ID
+#define BN_TRACE_BEGIN()                                                                                 \
+    const unsigned long long bn_tr_t0 = wall_clock64(), bn_tr_c0 = __builtin_readcyclecounter()
+#define BN_TRACE_END()                                                                                   \
+    do {                                                                                                 \
+        if (p.stamps && threadIdx.x == 0) {                                                              \
+            unsigned long long *r = p.stamps + 64 + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);   \
+            r[0] = bn_tr_t0; r[1] = wall_clock64(); r[2] = __builtin_readcyclecounter() - bn_tr_c0;      \
+            r[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
+        }                                                                                                \
+    } while (0)
 #else
 #define BN_STAMP(slot) do { } while (0)
 #define BN_STAMP_ANY(slot) do { } while (0)
+#define BN_TRACE_BEGIN() do { } while (0)
+#define BN_TRACE_END() do { } while (0)
 #endif
 
 // Geometry specialisations of the cell index ((p - origin) / res).floor().int()  (grid_map.py:195-209):
@@ -624,7 +637,7 @@ __device__ __forceinline__ void produce_pair(const SolveParams &p, const float *
     float e[4];
     const int t1 = min(t + 1, p.T - 1);
     if (EPS == kEpsPhilox) {
-        philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(t >> 1), e);
+        philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), e);
     } else if (EPS == kEpsKT2) {
         const float *row = eps + ((size_t)b * p.K + kk) * p.T * 2;
         const float2 v0 = *reinterpret_cast<const float2 *>(row + 2 * t);
@@ -669,10 +682,12 @@ template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
 __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BN_TRACE_BEGIN();
     if (blockIdx.x == p.nblk) {
         // pipelined mode: the extra workgroup computes the tail of the PREVIOUS solve (U*, X*, weights)
         // while the other workgroups roll out this one
         finish_body<GEO, LDSWIN, kRolloutThreads>(p, blockIdx.y, p.part_prev, p.cost_prev, p.state_prev, smem);
+        BN_TRACE_END();
         return;
     }
     const int T = p.T, K = p.K;
@@ -918,6 +933,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
         }
     }
     BN_STAMP(5);
+    BN_TRACE_END();
 }
 
 // ------------------------------------------------------------------------------
@@ -1126,7 +1142,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
                     z[2] = r0 <= T ? p.zc[((size_t)b * (T + 1) + r0) * K + kk] : 0.0f;
                     z[3] = r1 <= T ? p.zc[((size_t)b * (T + 1) + r1) * K + kk] : 0.0f;
                 } else {
-                    philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(q - nE), z);
+                    philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(q - nE), z);
                 }
                 Zt[r0 * 64 + lane] = z[0]; Zt[r1 * 64 + lane] = z[1];
                 Zc[r0 * 64 + lane] = z[2]; Zc[r1 * 64 + lane] = z[3];
@@ -1254,7 +1270,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
             zq[t & 1] = p.zt[((size_t)b * T + t) * K + kk];
             zq[2 + (t & 1)] = p.zc[((size_t)b * (T + 1) + t) * K + kk];
         } else if ((t & 1) == 0) {
-            philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(t >> 1), zq);
+            philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), zq);
         }
         const float u0 = Ul[(2 * t) * kUPad + lane], u1 = Ul[(2 * t + 1) * kUPad + lane];
         const int e = slip_cell_safe<GEO, false>(p, w, x, y);
@@ -1277,7 +1293,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         Xt[0] = x; Xt[Kp] = y; Xt[2 * Kp] = th;
     }
     if (p.zt) zq[2 + (T & 1)] = p.zc[((size_t)b * (T + 1) + T) * K + kk];
-    else if ((T & 1) == 0) philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)kk, (uint32_t)(T >> 1), zq);
+    else if ((T & 1) == 0) philox_slip_block(p.seed, p.solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(T >> 1), zq);
     const int eT = slip_cell_safe<GEO, false>(p, w, x, y);
     const float tT = trav_from_slip(mu[eT], sg[eT], zq[2 + (T & 1)]);
     const float dxT = x - gx, dyT = y - gy;
@@ -1346,14 +1362,14 @@ __global__ void gather_states_kernel(const float *__restrict__ X, const int *__r
     }
 }
 
-__global__ void philox_noise_kernel(float *__restrict__ eps, uint64_t seed, uint64_t solve, int b, int K, int T)
+__global__ void philox_noise_kernel(float *__restrict__ eps, uint64_t seed, uint64_t solve, int b, int K, int T, int k0)
 {   // eps (K, T, 2) of one instance, exactly the stream rollout_kernel<kEpsPhilox> consumes
     const int npair = (T + 1) / 2;                  // pair p = steps (2p, 2p+1)
     const size_t tot = (size_t)K * npair;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i / npair), pr = (int)(i - (size_t)k * npair);
         float z[4];
-        philox_eps_pair(seed, solve, (uint32_t)b, (uint32_t)k, (uint32_t)pr, z);
+        philox_eps_pair(seed, solve, (uint32_t)b, (uint32_t)(k + k0), (uint32_t)pr, z);
         const int t = 2 * pr;
         {
             eps[((size_t)k * T + t) * 2 + 0] = z[0];
@@ -1430,6 +1446,14 @@ bool sampled_fused(const SolveParams &p)
     const size_t need = sizeof(float) * sampled_lds_floats(p.T, p.WN);
     const size_t tail = finish_lds_bytes(p) + sizeof(float) * (8 * 2 * (size_t)p.T + 64);
     return p.slip_on && p.WN > 0 && need <= 160 * 1024 && tail <= need;
+}
+
+int rollout_blocks_per_cu(const SolveParams &p)
+{
+    int n = 0;
+    const size_t lds = rollout_lds_bytes(p);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rollout_kernel<kEpsPhilox, kGeoPow2Origin0, true, false>, kRolloutThreads, lds) != hipSuccess) return -1;
+    return n;
 }
 
 size_t rollout_lds_bytes(const SolveParams &p)
@@ -1551,9 +1575,9 @@ hipError_t launch_philox_slip(float *zt, float *zc, float *zo, uint64_t seed, ui
     return hipGetLastError();
 }
 
-hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, hipStream_t s)
+hipError_t launch_philox_noise(float *eps_kt2, uint64_t seed, uint64_t solve, int b, int K, int T, int k0, hipStream_t s)
 {
-    philox_noise_kernel<<<grid_for((size_t)K * ((T + 1) / 2)), 256, 0, s>>>(eps_kt2, seed, solve, b, K, T);
+    philox_noise_kernel<<<grid_for((size_t)K * ((T + 1) / 2)), 256, 0, s>>>(eps_kt2, seed, solve, b, K, T, k0);
     return hipGetLastError();
 }
 

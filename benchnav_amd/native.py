@@ -145,6 +145,23 @@ class NativeMPPI:
                                                     C.c_void_p(eps_ptr), kind, eps_ring, eps_stride))
 
     # -- DWA on the same transit / cost kernels -------------------------------------------------
+    # ---- K-sharded solve (one solve split over ranks; see benchnav_amd.sharding.ShardedMPPI) ----
+    def set_rollout_offset(self, first_rollout: int):
+        _capi.check(self._lib.bn_mppi_set_rollout_offset(self._h, first_rollout))
+
+    def shard_rollout_async_device(self, state_ptr: int, eps_ptr: Optional[int] = None, kind: int = _capi.BN_NOISE_PHILOX):
+        _capi.check(self._lib.bn_mppi_shard_rollout_async(self._h, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
+                                                          C.c_void_p(eps_ptr), kind))
+
+    def shard_partials(self):
+        """(device pointer, workgroups, floats per workgroup) of the shard's softmin partials."""
+        ptr, n, ps = C.c_void_p(), C.c_int32(), C.c_int32()
+        _capi.check(self._lib.bn_mppi_shard_partials(self._h, C.byref(ptr), C.byref(n), C.byref(ps)))
+        return ptr.value, n.value, ps.value
+
+    def shard_finish_async(self, all_partials_ptr: int, total_workgroups: int):
+        _capi.check(self._lib.bn_mppi_shard_finish_async(self._h, C.c_void_p(all_partials_ptr), total_workgroups))
+
     def dwa_solve(self, states, actions, stage_goal=None):
         """Roll out and cost constant-control candidates `actions` (B,NA,2) or (NA,2); see bn_mppi_dwa_solve.
         Returns dict(best_action (B,2), best_states (B,T+1,3), costs, weights (B,NA), states (B,NA,T+1,3), best_index (B))."""

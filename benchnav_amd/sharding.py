@@ -47,3 +47,102 @@ def gather_throughput(local_solves: int, local_seconds: float, device: Optional[
     tmax = float(rows[:, 1].max())
     return {"total_solves": total, "max_seconds": tmax, "solves_per_s": total / tmax if tmax > 0 else 0.0,
             "per_rank_solves": rows[:, 0].tolist(), "per_rank_seconds": rows[:, 1].tolist()}
+
+
+# ---------------------------------------------------------------------------------------------
+# Optional: ONE solve sharded over the ranks (K=16384 -> 2048 rollouts per GPU).
+# The only exchange is an all-gather of the per-workgroup softmin partials (max z, sum e, sum e*u): (2 + 2T) floats
+# per 64 rollouts, 207 KB in total at K=16384, T=100 -- one small, latency-bound collective per solve.
+# ---------------------------------------------------------------------------------------------
+def shard_rollouts(num_samples: int, world_size: int, rank: int):
+    """(first rollout, count) of this rank's contiguous shard; shards are multiples of 64 rollouts (one workgroup)."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    if num_samples % 64 != 0:
+        raise ValueError("a K-sharded solve needs num_samples to be a multiple of 64")
+    groups = shard_instances(num_samples // 64, world_size, rank)
+    if not groups:
+        raise ValueError(f"rank {rank} would own no rollouts: {num_samples} samples over {world_size} ranks")
+    return 64 * groups[0], 64 * len(groups)
+
+
+def merge_partials_reference(partials):
+    """NumPy statement of the exchange step: merge per-workgroup (max z, sum e, sum e*u[2T]) rows, in row order,
+    into (max z, sum e, U* (T,2)).  What bn_mppi_shard_finish_async computes on the device; used by the CPU tests."""
+    import numpy as np
+    p = np.asarray(partials, np.float64)
+    m = p[:, 0].max()
+    f = np.exp(p[:, 0] - m)
+    S = float((p[:, 1] * f).sum())
+    U = (p[:, 2:] * f[:, None]).sum(0) / S
+    return float(m), S, U.reshape(-1, 2).astype(np.float32)
+
+
+class ShardedMPPI:
+    """One MPPI solve whose rollouts are split over the ranks of a torch.distributed group (one process per GPU).
+
+    Every rank calls `solve(state)` with the same state and gets the same (U*, X*) -- bit-identical across ranks and
+    to the unsharded planner with the same seed -- and keeps the weights / trajectories of its own shard.
+    """
+
+    def __init__(self, horizon: int, num_samples: int, grid_size: int, resolution: float, group=None, **planner_kw):
+        import torch.distributed as dist
+        from .native import NativeMPPI
+        self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = group
+        self.world = self._dist.get_world_size(group) if self._dist else 1
+        self.rank = self._dist.get_rank(group) if self._dist else 0
+        self.first, self.count = shard_rollouts(num_samples, self.world, self.rank)
+        planner_kw.setdefault("stream", torch.cuda.current_stream().cuda_stream)
+        self.planner = NativeMPPI(horizon=horizon, num_samples=self.count, grid_size=grid_size, resolution=resolution,
+                                  num_instances=1, **planner_kw)
+        self.planner.set_rollout_offset(self.first)
+        self.T, self.K = horizon, num_samples
+        self._counts = [shard_rollouts(num_samples, self.world, r)[1] // 64 for r in range(self.world)]
+        self._gathered = torch.empty(sum(self._counts), 2 + 2 * horizon, dtype=torch.float32, device="cuda")
+        self._host_backend = bool(self._dist) and self._dist.get_backend(group) != "nccl"
+
+    @staticmethod
+    def _view(ptr, shape):
+        from .mppi import _DevArray
+        return torch.as_tensor(_DevArray(ptr, shape), device="cuda")
+
+    def _partials_tensor(self):
+        ptr, n, ps = self.planner.shard_partials()
+        return self._view(ptr, (n, ps))
+
+    def solve(self, state_dev: torch.Tensor, eps_dev: Optional[torch.Tensor] = None, kind: Optional[int] = None):
+        """state_dev: (3,) float32 on the GPU; eps_dev: this rank's slice of the noise or None (Philox in-kernel)."""
+        from . import _capi
+        if eps_dev is None:
+            self.planner.shard_rollout_async_device(state_dev.data_ptr())
+        else:
+            self.planner.shard_rollout_async_device(state_dev.data_ptr(), eps_dev.data_ptr(), _capi.BN_NOISE_DEVICE_KT2 if kind is None else kind)
+        mine = self._partials_tensor()
+        if self.world == 1:
+            self._gathered.copy_(mine)
+        else:
+            # equal-sized all-gather (ragged shards are padded to the largest), then the valid rows in rank order
+            maxc = max(self._counts)
+            host = self._host_backend                    # gloo rehearsal: stage through the host
+            send = torch.zeros(maxc, mine.shape[1], dtype=torch.float32, device="cpu" if host else "cuda")
+            send[:mine.shape[0]].copy_(mine)
+            recv = torch.empty(self.world * maxc, mine.shape[1], dtype=torch.float32, device=send.device)
+            self._dist.all_gather_into_tensor(recv, send, group=self.group)      # RCCL over xGMI with backend "nccl"
+            recv = recv.view(self.world, maxc, -1)
+            if min(self._counts) == maxc:
+                self._gathered.copy_(recv.reshape(-1, mine.shape[1]))
+            else:
+                self._gathered.copy_(torch.cat([recv[r, :c] for r, c in enumerate(self._counts)]))
+        self.planner.shard_finish_async(self._gathered.data_ptr(), self._gathered.shape[0])
+        return self
+
+    def results(self):
+        """(U* (T,2), X* (T+1,3)) of the latest solve as device tensors (views of planner memory, stream-ordered)."""
+        from . import _capi
+        us = self._view(self.planner.device_buffer(_capi.BN_BUF_USTAR)[0], (self.T, 2))
+        xs = self._view(self.planner.device_buffer(_capi.BN_BUF_XSTAR)[0], (self.T + 1, 3))
+        return us, xs
+
+    def close(self):
+        self.planner.close()

@@ -164,6 +164,20 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
  * other work on the same stream).  Noise block i is eps + (i % eps_ring) * eps_stride floats. */
 int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
+
+/* ---- K-sharded solve (optional row): ONE solve whose K_total rollouts are split over ranks ----------
+ * Every rank owns a handle with num_samples = its shard and rollouts [first_rollout, first_rollout + num_samples) of
+ * the global solve (the offset keys the Philox stream, so the union of the shards draws exactly the noise of the
+ * unsharded solve).  Per solve:
+ *   1. bn_mppi_shard_rollout_async            rollouts + costs of the shard, per-workgroup softmin partials
+ *   2. exchange                               all-gather bn_mppi_shard_partials over the ranks, rank order (RCCL)
+ *   3. bn_mppi_shard_finish_async             merge ALL partials in that order (bit-identical U* on every rank and equal
+ *                                             to the unsharded solve's), next mean, X*, and the shard's weights
+ * The reference has no multi-GPU path; the exchange is the log-sum-exp merge of mppi.py:193-199. */
+int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout);
+int bn_mppi_shard_rollout_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise);
+int bn_mppi_shard_partials(bn_mppi_t *h, const float **partials_device, int32_t *workgroups, int32_t *floats_per_workgroup);
+int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, int32_t total_workgroups);
 /*
  * Device-side closed loop: PlanetaryEnv.step (planetary_env.py:189-219) between consecutive solves, for
  * all B instances, without a host round trip per control step (the reference loop: test_mppi.py:171-198).

@@ -1,0 +1,138 @@
+"""GPU: one solve sharded over ranks by rollouts (optional row).  A single process plays every
+rank (one handle per shard on the same device, torch.cat as the all-gather); the exchange over torch.distributed
+is covered by tests/test_sharding_gloo.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _unsharded(K, T, G, inst, mean, seed, eps=None):
+    import torch
+    from benchnav_amd import NativeMPPI
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, store_controls=True, seed=seed, pipeline=False) as pl:
+        pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy()); pl.set_mean(mean)
+        us, xs = pl.solve(inst.start.numpy(), eps)
+        return dict(Ustar=us[0], Xstar=xs[0], w=pl.weights(), cost=pl.costs(), X=pl.states(), U=pl.controls())
+
+
+@pytest.mark.parametrize("K,T,world", [(4096, 50, 2), (4096, 50, 4), (16384, 100, 8), (1024, 33, 3)], ids=["w2", "w4", "c5-w8", "ragged-w3"])
+def test_sharded_solve_is_bit_identical_to_the_unsharded_one(K, T, world):
+    import torch
+    from benchnav_amd import NativeMPPI, _capi, synth
+    from benchnav_amd.sharding import shard_rollouts
+    G = 512 if K > 8192 else 256
+    inst = synth.make_instance(G, seed=4)
+    rng = np.random.default_rng(4)
+    mean = np.clip(rng.standard_normal((T, 2)) * 0.2 + [0.6, 0.0], [0, -1], [1, 1]).astype(np.float32)
+    ref = _unsharded(K, T, G, inst, mean, seed=123)
+    st = inst.start.cuda()
+    planners, parts = [], []
+    for r in range(world):
+        first, count = shard_rollouts(K, world, r)
+        pl = NativeMPPI(horizon=T, num_samples=count, grid_size=G, resolution=0.5, store_controls=True, seed=123, stream=0)
+        pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy()); pl.set_mean(mean); pl.set_rollout_offset(first)
+        pl.shard_rollout_async_device(st.data_ptr())
+        ptr, n, ps = pl.shard_partials()
+        assert n == count // 64 and ps == 2 + 2 * T
+        from benchnav_amd.mppi import _DevArray
+        parts.append(torch.as_tensor(_DevArray(ptr, (n, ps)), device="cuda"))
+        planners.append((pl, first, count))
+    gathered = torch.cat(parts).contiguous()
+    assert gathered.shape[0] == K // 64
+    outs = []
+    for pl, first, count in planners:
+        pl.shard_finish_async(gathered.data_ptr(), gathered.shape[0])
+        pl.sync()
+        us = pl.get_mean(0)
+        xs = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_XSTAR)[0], (T + 1, 3)), device="cuda").cpu().numpy()
+        outs.append((us, xs, pl.weights(), pl.costs(), pl.states(), pl.controls()))
+    for (pl, first, count), (us, xs, w, c, X, U) in zip(planners, outs):
+        sl = slice(first, first + count)
+        assert np.array_equal(U, ref["U"][sl]) and np.array_equal(X, ref["X"][sl]) and np.array_equal(c, ref["cost"][sl]), first
+        assert np.array_equal(us, ref["Ustar"]) and np.array_equal(xs, ref["Xstar"]), first      # same merge, same order
+        assert np.array_equal(w, ref["w"][sl]), first
+    assert abs(sum(float(o[2].astype(np.float64).sum()) for o in outs) - 1.0) < 1e-4
+    # second solve: every shard warm-starts from the same U*
+    for pl, _, _ in planners:
+        assert np.array_equal(pl.get_mean(0), ref["Ustar"])
+        pl.close()
+
+
+def test_shard_protocol_errors():
+    from benchnav_amd import NativeMPPI, synth
+    import torch
+    inst = synth.make_instance(64, seed=1)
+    st = inst.start.cuda()
+    with NativeMPPI(horizon=10, num_samples=128, grid_size=64, resolution=0.5, stream=0) as pl:
+        pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+        with pytest.raises(RuntimeError, match="no sharded solve"):
+            pl.shard_partials()
+        pl.shard_rollout_async_device(st.data_ptr())
+        with pytest.raises(RuntimeError, match="shard_finish"):
+            pl.solve_async_device(st.data_ptr())
+        ptr, n, ps = pl.shard_partials()
+        with pytest.raises(RuntimeError, match="every shard"):
+            pl.shard_finish_async(ptr, n - 1)
+        pl.shard_finish_async(ptr, n)            # world of one: its own partials
+        pl.sync()
+        w = pl.weights().astype(np.float64)
+        assert abs(w.sum() - 1) < 1e-5
+    with NativeMPPI(horizon=10, num_samples=128, grid_size=64, resolution=0.5, num_instances=2, stream=0) as pl:
+        pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+        with pytest.raises(RuntimeError, match="one instance"):
+            pl.shard_rollout_async_device(torch.stack([st, st]).data_ptr())
+
+
+def _dist_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from benchnav_amd import synth
+    from benchnav_amd.sharding import ShardedMPPI
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # one GPU on the box: RCCL refuses two ranks per device
+    try:
+        torch.cuda.set_device(0)
+        K, T, G = 2112, 50, 256      # 33 workgroups: ragged over two ranks (17 + 16)
+        inst = synth.make_instance(G, seed=4)
+        sp = ShardedMPPI(T, K, G, 0.5, seed=77)
+        sp.planner.set_map(inst.risk.numpy()); sp.planner.set_goal(inst.goal.numpy())
+        st = inst.start.cuda()
+        for _ in range(3):                                             # warm-started chain of sharded solves
+            sp.solve(st)
+        us, xs = sp.results()
+        torch.cuda.synchronize()
+        q.put((rank, sp.first, sp.count, us.cpu().numpy().tobytes(), xs.cpu().numpy().tobytes(), float(sp.planner.weights().astype("float64").sum())))
+        dist.barrier()
+        sp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_sharded_solve_over_torch_distributed():
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from benchnav_amd import NativeMPPI, synth
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    K, T, G = 2112, 50, 256      # 33 workgroups: ragged over two ranks (17 + 16)
+    inst = synth.make_instance(G, seed=4)
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=77, pipeline=False) as pl:
+        pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+        for _ in range(3):
+            us, xs = pl.solve(inst.start.numpy())
+    assert got[0][3] == got[1][3] == us[0].tobytes()                   # three warm-started solves later: still bit-identical
+    assert got[0][4] == got[1][4] == xs[0].tobytes()
+    assert abs(got[0][5] + got[1][5] - 1.0) < 1e-4                     # the shards' weights sum to one
