@@ -302,9 +302,41 @@ def main():
             el3 = timed_solves(pl3, state_dev, None, kind, n3, torch.cuda.synchronize)
             r3, f3, _ = pl3.kernel_ms()
             pl3.close()
-            out["sampled_slip"] = {"workload": f"mppi_solve K={K3} T={T} map={G}x{G}, slip ~ Normal(mean, std)[cell] drawn per lookup",
+            # algorithmic bytes (SURVEY.md 8d with in-kernel draws): mean + std maps, X, cost + weights, mean/state/U*/X*
+            bytes3 = 8 * G * G + 12 * K3 * (T + 1) + 8 * K3 + 28 * T + 24
+            traffic3 = None
+            if os.path.exists(tpath):
+                try:
+                    traffic3 = json.load(open(tpath)).get(f"rollout_sampled_K{K3}")
+                except Exception:
+                    traffic3 = None
+            out["sampled_slip"] = {"workload": f"BASELINE configs[2]: mppi_solve K={K3} T={T} map={G}x{G}, slip ~ Normal(mean, std)[cell] drawn per lookup",
                                    "value": n3 / el3, "unit": "solves/s", "us_per_solve": el3 / n3 * 1e6,
-                                   "draws_per_solve": K3 * (2 * T + 1) + T, "kernel_ms": r3, "finish_kernel_ms": f3}
+                                   "draws_per_solve": K3 * (2 * T + 1) + T,
+                                   "roofline": {"bound": "hbm", "achieved": bytes3 / (r3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": bytes3 / (r3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic3,
+                                                "kernel": "bn::rollout_sampled_kernel (one launch per solve: rollouts, ticket merge, previous tail)",
+                                                "kernel_ms": r3, "algorithmic_bytes_per_launch": bytes3}}
+        # ---- BASELINE configs[4] on one GPU: 512x512 map, K=16384, T=100 (LDS-tiled 43x43 window) ----
+        if world == 1:
+            K5, T5, G5 = 16384, 100, 512
+            inst5 = synth.make_instance(G5, seed=0, resolution=RES)
+            pl5 = NativeMPPI(horizon=T5, num_samples=K5, grid_size=G5, resolution=RES, device_id=local, profile=True,
+                             stream=torch.cuda.current_stream().cuda_stream)
+            pl5.set_map(inst5.risk.numpy()); pl5.set_goal(inst5.goal.numpy())
+            st5 = inst5.start.cuda()
+            n5 = max(50, a.steps // 20)
+            timed_solves(pl5, st5, None, kind, 30, torch.cuda.synchronize)
+            pl5.kernel_ms()
+            el5 = timed_solves(pl5, st5, None, kind, n5, torch.cuda.synchronize)
+            r5, f5, _ = pl5.kernel_ms()
+            bytes5 = pl5.algorithmic_bytes(injected_noise=False)
+            pl5.close()
+            out["config5_one_gpu"] = {"workload": f"BASELINE configs[4] on one GPU: mppi_solve K={K5} T={T5} map={G5}x{G5}",
+                                      "value": n5 / el5, "unit": "solves/s", "us_per_solve": el5 / n5 * 1e6,
+                                      "roofline": {"bound": "hbm", "achieved": bytes5 / (r5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": bytes5 / (r5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                   "kernel_ms": r5, "finish_kernel_ms": f5, "algorithmic_bytes_per_launch": bytes5}}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds)
     if dist is not None:

@@ -70,8 +70,10 @@ struct bn_mppi {
     float *d_slip_std = nullptr;     // sampled-slip mode
     float *d_ustar2[2] = {nullptr, nullptr}, *d_stats2[2] = {nullptr, nullptr};   // ticket-merge outputs by solve parity
     int *d_ticket = nullptr;
+    float *d_gpart = nullptr;
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
-    bool sampled_fused = false;      // one launch per solve: ticket merge + the previous tail as aux workgroup
+    bool ticket_mode = false;        // one launch per solve: ticket merge by the last workgroup + the previous tail as aux
+                                     // workgroup (sampled-slip kernel; deterministic kernel at K > 2048)
     bool slip_std_set = false;
     // device-side closed loop (bn_mppi_env_attach / bn_mppi_episode_async)
     float *d_lat_mean = nullptr, *d_lat_std = nullptr, *d_ep_states = nullptr, *d_ep_reward = nullptr, *d_env_state = nullptr;
@@ -129,7 +131,7 @@ int flush_tail(bn_mppi *h)
     bn::SolveParams p = h->p;
     const int cur = (int)((h->solves - 1) & 1);
     p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
-    if (h->sampled_fused) {
+    if (h->ticket_mode) {
         p.tail_merged = 1;
         p.ustar_prev = h->d_ustar2[cur]; p.stats_prev = h->d_stats2[cur];
     }
@@ -303,10 +305,22 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
             BN_HIP(hipMalloc((void **)&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4));
             BN_HIP(hipMalloc((void **)&h->d_stats2[q], (size_t)p.B * 2 * 4));
         }
-        BN_HIP(hipMalloc((void **)&h->d_ticket, (size_t)p.B * 4));
-        BN_HIP(hipMemset(h->d_ticket, 0, (size_t)p.B * 4));
-        p.ticket = h->d_ticket;
-        h->sampled_fused = !(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p);
+        BN_HIP(hipMalloc((void **)&h->d_ticket, (size_t)p.B * 65 * 4));
+        BN_HIP(hipMemset(h->d_ticket, 0, (size_t)p.B * 65 * 4));
+        BN_HIP(hipMalloc((void **)&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4));
+        p.ticket = h->d_ticket; p.gpart = h->d_gpart;
+        h->ticket_mode = !(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p);
+    } else if (!h->pipelined && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 1024 && bn::finish_lds_bytes(p) + 256 <= bn::rollout_lds_bytes(p)) {
+        // K > 2048: too many partials for every workgroup to re-merge; the last workgroup of a launch merges them
+        for (int q = 0; q < 2; ++q) {
+            BN_HIP(hipMalloc((void **)&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4));
+            BN_HIP(hipMalloc((void **)&h->d_stats2[q], (size_t)p.B * 2 * 4));
+        }
+        BN_HIP(hipMalloc((void **)&h->d_ticket, (size_t)p.B * 65 * 4));
+        BN_HIP(hipMemset(h->d_ticket, 0, (size_t)p.B * 65 * 4));
+        BN_HIP(hipMalloc((void **)&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4));
+        p.gpart = h->d_gpart;
+        h->ticket_mode = true;             // p.ticket stays null in h->p: only the one-launch path selects the ticket kernel
     }
     BN_HIP(hipDeviceSynchronize());
     *out = h;
@@ -323,7 +337,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
                     h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
                     h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
-                    h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket};
+                    h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket, h->d_gpart};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -465,7 +479,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     } else if (h->shard_pending) {
         return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
     }
-    const bool one_launch = !shard_rollout && (h->pipelined || h->sampled_fused);
+    const bool one_launch = !shard_rollout && (h->pipelined || h->ticket_mode);
     const bool prof_grouped = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && one_launch;
     const bool prof = (h->cfg.flags & BN_FLAG_PROFILE) != 0 && !one_launch;
     hipEvent_t *ev = nullptr;
@@ -515,14 +529,16 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     p.mean_from_part = 0;
     p.tail_solve = p.solve;
     if (p.slip_on && !h->slip_std_set) return fail(BN_ERR_STATE, "bn_mppi_set_slip_std must precede solve in sampled-slip mode");
-    if (h->sampled_fused && !shard_rollout) {
+    if (h->ticket_mode && !shard_rollout) {
         // one launch: the rollouts, the ticket merge of this solve, and the previous solve's tail as aux workgroup
         p.have_prev = h->tail_pending ? 1 : 0;
         p.tail_merged = 1;
         p.tail_solve = p.solve - 1;
         p.ustar_cur = h->d_ustar2[cur]; p.stats_cur = h->d_stats2[cur];
         p.ustar_prev = h->d_ustar2[prev]; p.stats_prev = h->d_stats2[prev];
-        BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
+        p.ticket = h->d_ticket;
+        if (p.slip_on) BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
+        else BN_HIP(bn::launch_rollout(p, mode, h->stream));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
         h->tail_pending = true;
@@ -889,7 +905,7 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!(h->cfg.flags & BN_FLAG_PROFILE)) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_PROFILE");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
-    if (h->pipelined || h->sampled_fused) {
+    if (h->pipelined || h->ticket_mode) {
         // close the open group with one more event *before* the flush, then average complete groups only
         const int open = h->prof_in_group;
         if (h->ev_used + 1 > h->ev.size()) {

@@ -69,7 +69,8 @@ struct SolveParams {
     const float *zt, *zc, *zo;         // injected standard normals: transit (B,T,K), cost (B,T+1,K), X* (B,T); or nullptr: Philox
     // fused tail of the sampled kernel: the last workgroup of an instance to finish (ticket) merges the partials itself;
     // weights / X* of that solve are written by the aux workgroup of the NEXT launch, or by the stand-alone tail
-    int *ticket;                       // (B,) workgroups of this launch done so far; reset by the last one
+    int *ticket;                       // (B, 65) ticket counters (see ticket_merge); reset by the workgroups that draw the last ones
+    float *gpart;                      // (B, 64, 2+2T) group rows of the two-level merge (more than 64 workgroups)
     float *ustar_cur, *stats_cur;      // (B, T, 2), (B, 2): merge outputs of this solve (double-buffered by solve parity)
     const float *ustar_prev, *stats_prev;   // merge outputs of the solve whose tail this launch / the stand-alone tail writes
     int tail_merged;                   // the tail reads (ustar_prev, stats_prev) instead of merging `part`

@@ -315,21 +315,68 @@ struct MergeLoads { float v[kMergePrefetch]; float mi, si; int j; };
 
 // Issue every load of the few-blocks merge (nblk <= 64) without consuming any: lets the caller put
 // other memory traffic (the window staging) in flight underneath.
+template <bool AGENT = false>
 __device__ __forceinline__ MergeLoads merge_issue(const float *__restrict__ part, int nblk, int T, int tid)
 {
+#define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
     const int PS = 2 + 2 * T;
     const int lane = tid & 63;
     MergeLoads L;
     L.j = tid < 2 * T ? tid : 0;
 #pragma unroll
-    for (int i = 0; i < kMergePrefetch; ++i) L.v[i] = part[(size_t)min(i, nblk - 1) * PS + 2 + L.j];
+    for (int i = 0; i < kMergePrefetch; ++i) L.v[i] = BN_PLD((size_t)min(i, nblk - 1) * PS + 2 + L.j);
     const bool has = lane < nblk;
-    L.mi = has ? part[(size_t)lane * PS] : -INFINITY;
-    L.si = has ? part[(size_t)lane * PS + 1] : 0.0f;
+    L.mi = has ? BN_PLD((size_t)lane * PS) : -INFINITY;
+    L.si = has ? BN_PLD((size_t)lane * PS + 1) : 0.0f;
     return L;
+#undef BN_PLD
 }
 
-template <int NT, bool AGENT = false>
+// Two-level merge for more than 64 partial rows (K > 4096): rows are first merged in groups of kGroupRows
+// consecutive rows, each relative to its group's max -- by whichever wave(s) get the job: a wave of the stand-alone
+// tail, or the waves of the last rollout workgroup of the group to finish (ticket) -- then the group rows are merged
+// like ordinary partials.  One definition for every caller, so the result does not depend on who ran it.
+constexpr int kGroupRows = 16;
+
+// Rows [row0, row0 + nrows) of `part` -> one row `gout` = (group max, sum e, sum e*u[2T]).  One wave; it handles the
+// 64-column blocks cb0, cb0 + cbstep, ... (several waves may share a group: they derive identical scales).
+template <bool AGENT, bool AGENT_STORE>
+__device__ __forceinline__ void merge_group(const float *__restrict__ part, int row0, int nrows, int T, int lane, int cb0,
+                                            int cbstep, float *gout)
+{
+#define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
+#define BN_PST(ptr, val) do { if (AGENT_STORE) store_agent((ptr), (val)); else *(ptr) = (val); } while (0)
+    const int PS = 2 + 2 * T;
+    const bool has = lane < nrows;
+    const float mi = has ? BN_PLD((size_t)(row0 + lane) * PS) : -INFINITY;
+    const float si = has ? BN_PLD((size_t)(row0 + lane) * PS + 1) : 0.0f;
+    float v[kGroupRows];
+    int jj = lane + 64 * cb0;
+#pragma unroll
+    for (int r = 0; r < kGroupRows; ++r) v[r] = (r < nrows && jj < 2 * T) ? BN_PLD((size_t)(row0 + r) * PS + 2 + jj) : 0.0f;
+    const float mg = wave_max(mi);
+    const float f = has ? expf(mi - mg) : 0.0f;
+    const float sg = wave_sum(si * f);
+    const int fb = __float_as_int(f);
+    for (int cb = cb0;;) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < kGroupRows; ++r) acc = __builtin_fmaf(v[r], __int_as_float(__builtin_amdgcn_readlane(fb, r)), acc);   // f == 0 past nrows
+        if (jj < 2 * T) BN_PST(gout + 2 + jj, acc);
+        cb += cbstep;
+        if (64 * cb >= 2 * T) break;
+        jj = lane + 64 * cb;
+#pragma unroll
+        for (int r = 0; r < kGroupRows; ++r) v[r] = (r < nrows && jj < 2 * T) ? BN_PLD((size_t)(row0 + r) * PS + 2 + jj) : 0.0f;
+    }
+    if (cb0 == 0 && lane == 0) { BN_PST(gout, mg); BN_PST(gout + 1, sg); }
+#undef BN_PLD
+#undef BN_PST
+}
+
+// BIG = false leaves the two-level code out of callers that never see more than 64 rows (the rollout kernels'
+// prologue / aux / ticket merges): it costs them registers.
+template <int NT, bool AGENT = false, bool BIG = false>
 __device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
                                                float *red, int tid, float &m_out, float &S_out, const MergeLoads *pre)
 {
@@ -341,7 +388,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         // Few blocks (K <= 4096): every wave reduces the nblk (max, sum) pairs itself -- same inputs,
         // same operations, so all waves (and all workgroups) hold identical m, S and scales -- and all
         // loads are issued before the first use: one memory round trip, one barrier.
-        const MergeLoads L = pre ? *pre : merge_issue(part, nblk, T, tid);
+        const MergeLoads L = pre ? *pre : merge_issue<AGENT>(part, nblk, T, tid);
         m = wave_max(L.mi);
         const float f = lane < nblk ? expf(L.mi - m) : 0.0f;       // scale of block `lane`; 0 past nblk
         S = wave_sum(L.si * f);
@@ -361,7 +408,20 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
             us[jj] = acc / S;
         }
 #undef BN_SCALE
-    } else if constexpr (NT < 512) {
+    } else if (BIG && nblk <= 64 * kGroupRows) {
+        // two-level (see merge_group): groups dealt to the waves, group rows in LDS, then the few-rows merge above
+        constexpr int NW = NT / 64;
+        const int ng = (nblk + kGroupRows - 1) / kGroupRows;
+        float *grows = red + 32;                         // ng x PS
+        for (int g = tid >> 6; g < ng; g += NW)
+            if constexpr (BIG) merge_group<AGENT, false>(part, g * kGroupRows, min(kGroupRows, nblk - g * kGroupRows), T, lane, 0, 1, grows + (size_t)g * PS);
+        __syncthreads();
+        merge_partials<NT, false, false>(grows, ng, T, us, sc, red, tid, m, S, nullptr);
+        m_out = m;
+        S_out = S;
+        return;
+    } else {
+        // more than 1024 workgroups (K > 65536): plain column sums in row order (independent of NT as well)
         float mm = -INFINITY;
         for (int i = tid; i < nblk; i += NT) mm = fmaxf(mm, BN_PLD((size_t)i * PS));
         m = block_reduce<NT>(mm, red, tid, true);
@@ -377,73 +437,6 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
             for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), sc[i], acc);
             us[jj] = acc / S;
         }
-    } else {
-        // Many blocks (the stand-alone tail of a large-K solve, NT = 1024; the ticket merge of the sampled kernel, 512): the part rows are split over the
-        // waves (row i -> wave i mod NW) and every load a thread needs -- its block's (max, sum) pair and the
-        // first kPreRows x kPreCols of its tile -- is issued before the first reduction: one memory round trip.
-        constexpr int NW = NT / 64, kPreRows = NT >= 1024 ? 8 : 16, kPreCols = 2;     // covers nblk <= 128 (K = 8192) at T <= 64
-        const int wv = tid >> 6;
-        float *accw = red + 32;                          // NW x 2T per-wave partial sums
-        const bool has = tid < nblk;
-        const float mi = has ? BN_PLD((size_t)tid * PS) : -INFINITY;
-        const float si = has ? BN_PLD((size_t)tid * PS + 1) : 0.0f;
-        float pre[kPreRows][kPreCols];
-#pragma unroll
-        for (int r = 0; r < kPreRows; ++r)
-#pragma unroll
-            for (int c = 0; c < kPreCols; ++c) {
-                const int i = wv + NW * r, jj = lane + 64 * c;
-                pre[r][c] = (i < nblk && jj < 2 * T) ? BN_PLD((size_t)i * PS + 2 + jj) : 0.0f;
-            }
-        float mm = mi;
-        for (int i = tid + NT; i < nblk; i += NT) mm = fmaxf(mm, BN_PLD((size_t)i * PS));
-        m = block_reduce<NT>(mm, red, tid, true);
-        float s = 0.0f;
-        if (has) {
-            const float f = expf(mi - m);
-            sc[tid] = f;
-            s = si * f;
-        }
-        for (int i = tid + NT; i < nblk; i += NT) {
-            const float f = expf(BN_PLD((size_t)i * PS) - m);
-            sc[i] = f;
-            s += BN_PLD((size_t)i * PS + 1) * f;
-        }
-        S = block_reduce<NT>(s, red, tid, false);        // the barrier inside also publishes sc[]
-        float acc[kPreCols] = {};
-#pragma unroll
-        for (int r = 0; r < kPreRows; ++r) {
-            const int i = wv + NW * r;
-            if (i < nblk) {
-                const float f = sc[i];
-#pragma unroll
-                for (int c = 0; c < kPreCols; ++c) acc[c] = __builtin_fmaf(pre[r][c], f, acc[c]);
-            }
-        }
-#pragma unroll 4
-        for (int i = wv + NW * kPreRows; i < nblk; i += NW) {
-            const float f = sc[i];
-#pragma unroll
-            for (int c = 0; c < kPreCols; ++c) {
-                const int jj = lane + 64 * c;
-                acc[c] = __builtin_fmaf(jj < 2 * T ? BN_PLD((size_t)i * PS + 2 + jj) : 0.0f, f, acc[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < kPreCols; ++c)
-            if (lane + 64 * c < 2 * T) accw[wv * 2 * T + lane + 64 * c] = acc[c];
-        for (int jj = lane + 64 * kPreCols; jj < 2 * T; jj += 64) {       // columns past the prefetched ones (T > 64)
-            float a = 0.0f;
-            for (int i = wv; i < nblk; i += NW) a = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), sc[i], a);
-            accw[wv * 2 * T + jj] = a;
-        }
-        __syncthreads();
-        for (int jj = tid; jj < 2 * T; jj += NT) {
-            float a = 0.0f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) a += accw[w * 2 * T + jj];
-            us[jj] = a / S;
-        }
     }
     __syncthreads();
     m_out = m;
@@ -453,8 +446,8 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 
 // The tail of one solve of instance b: U* (and the next mean), softmin statistics, normalised weights,
 // a stable copy of the costs, and the batch-1 rollout X* of U*.  NT threads (320 as the aux workgroup, 1024 stand-alone for large K).
-// LDS: [ window | ustar 2T | scale nblk | red 32 | per-wave sums NT/64 x 2T | sampled mode: draws, (mean, std) window ]
-template <int GEO, bool LDSWIN, int NT>
+// LDS: [ window | ustar 2T | scale nblk | red 32 | group rows ceil(nblk/16) x (2+2T) if nblk > 64 | sampled mode: draws, (mean, std) window ]
+template <int GEO, bool LDSWIN, int NT, bool BIG = false>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
 {
@@ -490,7 +483,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         S = p.stats_prev[b * 2 + 1];
         __syncthreads();
     } else {
-        merge_partials<NT>(part, nblk, T, us, sc, red, tid, m, S, nullptr);
+        merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, nullptr);
         for (int j = tid; j < 2 * T; j += NT) {
             p.ustar[(size_t)b * 2 * T + j] = us[j];
             p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
@@ -522,7 +515,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         // sampled-slip mode: the optimal rollout draws a fresh slip per transit as well (mppi.py:202-214 with
         // traversability_model.py:65-69).  Draws and the (mean, std) window are staged by all threads first.
         const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
-        float *zol = red + 32 + (NT / 64) * 2 * T;                      // T + 4 draws
+        float *zol = red + 32 + ((nblk > 64 && nblk <= 64 * kGroupRows) ? ((nblk + kGroupRows - 1) / kGroupRows) * PS : 0);                      // T + 4 draws
         float2 *win2 = reinterpret_cast<float2 *>((reinterpret_cast<uintptr_t>(zol + ((T + 7) & ~3)) + 7) & ~(uintptr_t)7);
         if (p.zo) {
             for (int t = tid; t < T; t += NT) zol[t] = p.zo[(size_t)b * T + t];
@@ -624,6 +617,59 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     }
 }
 
+// Ticket merge: every workgroup of instance b publishes its partials, takes a ticket, and the one that draws the
+// last ticket merges all of them (fixed order: the result does not depend on which workgroup that is) into
+// U* = the next mean, plus the softmin statistics the tail needs for the weights.  Saves the merge launch.
+// With more than 64 workgroups the merge is the two-level one (merge_group): the last workgroup of each group of 16
+// merges its group (its waves split the columns: one memory round trip), the last group to finish merges the groups.
+// The partials travel as device-scope sc1 stores / loads (store_agent / load_agent): once every wave has seen its
+// stores acknowledged (vmcnt 0) and the workgroup has met at the barrier, the ticket is taken.  No __threadfence:
+// that writes back / invalidates the whole L2 once per workgroup (measured: +18 us per launch at 128 workgroups).
+// Ticket counters: kTicketStride ints per instance, [0] = groups (or workgroups) done, [1 + g] = workgroups of group g.
+// LDS scratch: [ us 2T | sc nblk | red 32 | flag ].  Needs nblk <= 1024 (two levels).
+constexpr int kTicketStride = 1 + 64;
+
+template <int NT>
+__device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, float *scratch)
+{
+    const int T = p.T, tid = threadIdx.x, PS = 2 + 2 * p.T;
+    float *us = scratch, *sc = us + 2 * T, *red = sc + p.nblk;
+    int *flag = reinterpret_cast<int *>(red + 32);       // at most 64 rows reach merge_partials here: no group rows in LDS
+    int *ticket = p.ticket + (size_t)b * kTicketStride;
+    const float *part = p.part + (size_t)b * p.nblk * PS;
+    const float *rows = part;
+    int nrows = p.nblk;
+    if (p.nblk > 64) {
+        const int g = blockIdx.x / kGroupRows, ng = (p.nblk + kGroupRows - 1) / kGroupRows;
+        const int in_group = min(kGroupRows, p.nblk - g * kGroupRows);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *flag = (atomicAdd(ticket + 1 + g, 1) == in_group - 1) ? 1 : 0;
+        __syncthreads();
+        if (!*flag) return;
+        if (tid == 0) ticket[1 + g] = 0;
+        float *grow = p.gpart + ((size_t)b * 64 + g) * PS;
+        merge_group<true, true>(part, g * kGroupRows, in_group, T, tid & 63, tid >> 6, NT / 64, grow);
+        rows = p.gpart + (size_t)b * 64 * PS;
+        nrows = ng;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *flag = (atomicAdd(ticket, 1) == nrows - 1) ? 1 : 0;
+    __syncthreads();
+    if (!*flag) return;
+    BN_STAMP_ANY(6);
+    if (tid == 0) ticket[0] = 0;                       // ready for the next launch (ordered by the stream)
+    float m, S;
+    merge_partials<NT, true, false>(rows, nrows, T, us, sc, red, tid, m, S, nullptr);
+    for (int j = tid; j < 2 * T; j += NT) {
+        p.ustar_cur[(size_t)b * 2 * T + j] = us[j];
+        p.mean[(size_t)b * 2 * T + j] = us[j];         // _previous_action_seq = U*, no shift (mppi.py:217)
+    }
+    if (tid == 0) { p.stats_cur[b * 2 + 0] = m; p.stats_cur[b * 2 + 1] = S; }
+    BN_STAMP_ANY(7);
+}
+
 // Workgroup barrier that only drains LDS traffic: global stores of the consumer wave stay in flight.
 #define BN_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -678,7 +724,7 @@ __device__ __forceinline__ void produce_pair(const SolveParams &p, const float *
 // LDS: [ ring 2 x TU x 64 x float4 | final state + control-cost sum 5 x 64 | e 64 | window WN*WN | mean 2T | mean*inv_var 2T |
 //        control tile 2T x 65 ]
 // ------------------------------------------------------------------------------
-template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
+template <int EPS, int GEO, bool LDSWIN, bool STORE_U, bool TICKET>
 __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -917,7 +963,8 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
         el[lane] = e;
         if (lane == 0) {
             float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
-            part[0] = zmax; part[1] = esum;
+            if (TICKET) { store_agent(part, zmax); store_agent(part + 1, esum); }
+            else { part[0] = zmax; part[1] = esum; }
         }
     }
     BN_BAR();
@@ -929,10 +976,12 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
             float acc = 0.0f;
 #pragma unroll 16
             for (int q = 0; q < kRolloutsPerBlock; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
-            part[2 + j] = acc;
+            if (TICKET) store_agent(part + 2 + j, acc); else part[2 + j] = acc;
         }
     }
     BN_STAMP(5);
+    // sizes the pipelined prologue merge does not take (K > 2048): the last workgroup merges, the tail rides in the next launch
+    if (TICKET) ticket_merge<kRolloutThreads>(p, b, smem);
     BN_TRACE_END();
 }
 
@@ -944,7 +993,7 @@ template <int GEO, bool LDSWIN, int NT>
 __global__ __launch_bounds__(NT) void finish_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    finish_body<GEO, LDSWIN, NT>(p, blockIdx.x, p.part, p.cost, p.state, smem);
+    finish_body<GEO, LDSWIN, NT, true>(p, blockIdx.x, p.part, p.cost, p.state, smem);
 }
 
 // ------------------------------------------------------------------------------
@@ -1043,37 +1092,6 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
 // LDS: [ slot rows (T+1) x 64 float4 | window WN^2 float2 | Zt TP x 64 | Zc TP x 64 | controls 2T x 65 | mean 2T |
 //        mean*inv_var 2T | e 64 | control cost 64 ],  TP = T+1 rounded up to even.
 // ------------------------------------------------------------------------------
-// Ticket merge: every workgroup of instance b publishes its partials, takes a ticket, and the one that draws the
-// last ticket merges all of them (fixed block order: the result does not depend on which workgroup that is) into
-// U* = the next mean, plus the softmin statistics the tail needs for the weights.  Saves the merge launch.
-// LDS scratch: [ us 2T | sc nblk | red 32 | per-wave sums (NT/64) x 2T | flag ].
-template <int NT>
-__device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, float *scratch)
-{
-    const int T = p.T, tid = threadIdx.x;
-    float *us = scratch, *sc = us + 2 * T, *red = sc + p.nblk;
-    int *flag = reinterpret_cast<int *>(red + 32 + (NT / 64) * 2 * T);
-    // The partials were stored with store_agent (write-through to the device coherence point); once every wave has
-    // seen them acknowledged (vmcnt 0) and the workgroup has met at the barrier, the ticket is taken.  The last
-    // workgroup reads all partials with load_agent.  No __threadfence: that would write back / invalidate the
-    // whole L2 once per workgroup (measured: +18 us per launch at 128 workgroups).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) *flag = (atomicAdd(p.ticket + b, 1) == p.nblk - 1) ? 1 : 0;
-    __syncthreads();
-    if (!*flag) return;
-    BN_STAMP_ANY(6);
-    if (tid == 0) p.ticket[b] = 0;                     // ready for the next launch (ordered by the stream)
-    float m, S;
-    merge_partials<NT, true>(p.part + (size_t)b * p.nblk * (2 + 2 * T), p.nblk, T, us, sc, red, tid, m, S, nullptr);
-    for (int j = tid; j < 2 * T; j += NT) {
-        p.ustar_cur[(size_t)b * 2 * T + j] = us[j];
-        p.mean[(size_t)b * 2 * T + j] = us[j];         // _previous_action_seq = U*, no shift (mppi.py:217)
-    }
-    if (tid == 0) { p.stats_cur[b * 2 + 0] = m; p.stats_cur[b * 2 + 1] = S; }
-    BN_STAMP_ANY(7);
-}
-
 constexpr int kSampledWaves = 8;
 constexpr int kSampledThreads = 64 * kSampledWaves;
 
@@ -1230,7 +1248,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         store_agent(part + 2 + j, acc);
     }
     BN_STAMP(5);
-    ticket_merge<kSampledThreads>(p, b, smem);          // the slot rows are dead: their LDS is the merge scratch
+    if (p.ustar_cur) ticket_merge<kSampledThreads>(p, b, smem);   // one-launch mode; the slot rows are dead: their LDS is the merge scratch
 }
 
 // The same solve without the LDS window (BN_FLAG_NO_LDS_WINDOW, or a window/horizon too large for the LDS):
@@ -1399,9 +1417,16 @@ template <int EPS, int GEO, bool LDSWIN, bool STORE_U>
 hipError_t launch_rollout_u(const SolveParams &p, hipStream_t s)
 {
     const size_t lds = rollout_lds_bytes(p);
-    hipError_t e = ensure_lds(rollout_kernel<EPS, GEO, LDSWIN, STORE_U>, lds);
-    if (e != hipSuccess) return e;
-    rollout_kernel<EPS, GEO, LDSWIN, STORE_U><<<dim3(p.nblk + (p.have_prev ? 1 : 0), p.B), dim3(kRolloutThreads), lds, s>>>(p);
+    const dim3 grid(p.nblk + (p.have_prev ? 1 : 0), p.B);
+    if (p.ticket) {
+        hipError_t e = ensure_lds(rollout_kernel<EPS, GEO, LDSWIN, STORE_U, true>, lds);
+        if (e != hipSuccess) return e;
+        rollout_kernel<EPS, GEO, LDSWIN, STORE_U, true><<<grid, dim3(kRolloutThreads), lds, s>>>(p);
+    } else {
+        hipError_t e = ensure_lds(rollout_kernel<EPS, GEO, LDSWIN, STORE_U, false>, lds);
+        if (e != hipSuccess) return e;
+        rollout_kernel<EPS, GEO, LDSWIN, STORE_U, false><<<grid, dim3(kRolloutThreads), lds, s>>>(p);
+    }
     return hipGetLastError();
 }
 
@@ -1444,15 +1469,15 @@ bool sampled_fused(const SolveParams &p)
 {
     // the multi-wave kernel needs the LDS window and room for its tiles; its LDS also holds the aux tail / merge scratch
     const size_t need = sizeof(float) * sampled_lds_floats(p.T, p.WN);
-    const size_t tail = finish_lds_bytes(p) + sizeof(float) * (8 * 2 * (size_t)p.T + 64);
-    return p.slip_on && p.WN > 0 && need <= 160 * 1024 && tail <= need;
+    const size_t tail = finish_lds_bytes(p) + sizeof(float) * 64;
+    return p.slip_on && p.WN > 0 && need <= 160 * 1024 && tail <= need && p.nblk <= 1024;
 }
 
 int rollout_blocks_per_cu(const SolveParams &p)
 {
     int n = 0;
     const size_t lds = rollout_lds_bytes(p);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rollout_kernel<kEpsPhilox, kGeoPow2Origin0, true, false>, kRolloutThreads, lds) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rollout_kernel<kEpsPhilox, kGeoPow2Origin0, true, false, false>, kRolloutThreads, lds) != hipSuccess) return -1;
     return n;
 }
 
@@ -1464,8 +1489,8 @@ size_t rollout_lds_bytes(const SolveParams &p)
 size_t finish_lds_bytes(const SolveParams &p)
 {
     const size_t slip = p.slip_on ? 2 * (size_t)p.WN * p.WN + (size_t)p.T + 16 : 0;    // (mean, std) window + the draws of X*
-    const size_t waves = (p.nblk > 32 ? kWideFinishThreads : kFinishThreads) / 64;       // per-wave partial sums of the wide merge
-    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + (size_t)p.nblk + 32 + waves * 2 * (size_t)p.T + slip);
+    const size_t groups = (p.nblk > 64 && p.nblk <= 64 * 16) ? (size_t)((p.nblk + 15) / 16) * (2 + 2 * (size_t)p.T) : 0;   // two-level merge rows
+    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + (size_t)p.nblk + 32 + groups + slip);
 }
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)
