@@ -292,3 +292,29 @@ def _dev(pl, T, B):
     from benchnav_amd import _capi
     from benchnav_amd.mppi import _DevArray
     return _DevArray(pl.device_buffer(_capi.BN_BUF_XSTAR)[0], (B, T + 1, 3))
+
+
+@pytest.mark.parametrize("K,T,B,sampled", [(8192, 50, 2, False), (8192, 50, 1, True), (2112, 20, 7, False)], ids=["K8192-B2", "sampled", "B7"])
+def test_ticket_handoff_stress(K, T, B, sampled):
+    """The in-launch hand-off of the partials (sc1 stores -> ticket -> sc1 loads, possibly across XCDs) under load:
+    300 back-to-back warm-started solves must end exactly where the two-launch chain ends; one stale word anywhere
+    would show in the final mean (every solve's U* feeds the next)."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    G, n = 256, 300
+    inst = synth.make_instance(G, seed=8)
+    st = torch.from_numpy(np.tile(inst.start.numpy(), (B, 1)) + 0.1 * np.arange(B)[:, None]).float().cuda()
+    torch.cuda.synchronize()
+    got = {}
+    for mode in ("one_launch", "two_launch"):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, shared_map=True, seed=11,
+                        sampled_slip=sampled, pipeline=(mode == "one_launch")) as pl:
+            pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+            if sampled:
+                pl.set_slip_std(synth.slip_std_map(G, seed=8).numpy())
+            pl.solve_n_async_device(n, st.data_ptr())
+            pl.sync()
+            got[mode] = [(pl.get_mean(b), pl.costs(b), pl.weights(b)) for b in range(B)]
+    for b in range(B):
+        for a_, b_ in zip(got["one_launch"][b], got["two_launch"][b]):
+            assert np.array_equal(a_, b_), b
