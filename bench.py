@@ -332,10 +332,16 @@ def main():
             r5, f5, _ = pl5.kernel_ms()
             bytes5 = pl5.algorithmic_bytes(injected_noise=False)
             pl5.close()
+            traffic5 = None
+            if os.path.exists(tpath):
+                try:
+                    traffic5 = json.load(open(tpath)).get(f"rollout_K{K5}_T{T5}_G{G5}")
+                except Exception:
+                    traffic5 = None
             out["config5_one_gpu"] = {"workload": f"BASELINE configs[4] on one GPU: mppi_solve K={K5} T={T5} map={G5}x{G5}",
                                       "value": n5 / el5, "unit": "solves/s", "us_per_solve": el5 / n5 * 1e6,
                                       "roofline": {"bound": "hbm", "achieved": bytes5 / (r5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": bytes5 / (r5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                   "frac": bytes5 / (r5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic5,
                                                    "kernel_ms": r5, "finish_kernel_ms": f5, "algorithmic_bytes_per_launch": bytes5}}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds)
