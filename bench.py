@@ -269,7 +269,23 @@ def main():
                     traffic_b = json.load(open(tpath)).get(f"rollout_{a.noise}_B{B}")
                 except Exception:
                     traffic_b = None
-            out["batched"] = {"instances_per_launch": B, "value": B * nb / elb, "unit": "solves/s",
+            # a launch large enough for the one-wave throughput kernel (auto-selected above ~1500 workgroups)
+            BL = 256
+            pll = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=BL, shared_map=True, device_id=local,
+                             profile=True, stream=torch.cuda.current_stream().cuda_stream)
+            pll.set_map(inst.risk.numpy()); pll.set_goal(inst.goal.numpy())
+            stl = torch.stack([inst.start] * BL).cuda()
+            timed_solves(pll, stl, None, kind, 30, torch.cuda.synchronize)
+            pll.kernel_ms()
+            nl = max(30, a.steps // 40)
+            ell = timed_solves(pll, stl, None, kind, nl, torch.cuda.synchronize)
+            rl, _, _ = pll.kernel_ms()
+            bytes_l = pll.algorithmic_bytes(injected_noise=False) * BL
+            pll.close()
+            large = {"instances_per_launch": BL, "value": BL * nl / ell, "unit": "solves/s", "ms_per_launch": ell / nl * 1e3,
+                     "kernel": "bn::rollout_wave_kernel (one wave per 64 rollouts)", "kernel_ms": rl,
+                     "hbm_frac": bytes_l / (rl * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_l}
+            out["batched"] = {"instances_per_launch": B, "value": B * nb / elb, "unit": "solves/s", "large_batch": large,
                               "ms_per_launch": elb / nb * 1e3,
                               "roofline": {"bound": "hbm", "achieved": bytes_b / (rb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": bytes_b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -21,6 +21,8 @@ BN_MEM_HOST, BN_MEM_DEVICE = 0, 1
 BN_FLAG_STORE_CONTROLS, BN_FLAG_SHARED_MAP, BN_FLAG_NO_LDS_WINDOW, BN_FLAG_PROFILE, BN_FLAG_PRIVATE_STREAM = 1, 2, 4, 8, 16
 BN_FLAG_NO_PIPELINE = 32
 BN_FLAG_SAMPLED_SLIP = 64
+BN_FLAG_WAVE_KERNEL = 128
+BN_FLAG_ROLE_KERNEL = 256
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
 ABI_VERSION = 1
 

@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int kProfGroup = 10;
+constexpr size_t kWaveKernelMinWorkgroups = 1536;   // measured crossover (tools/wave_vs_role.py): ~96 instances of K=1024
 thread_local std::string g_last_error;
 
 int fail(int code, const char *fmt, ...)
@@ -71,6 +72,7 @@ struct bn_mppi {
     float *d_ustar2[2] = {nullptr, nullptr}, *d_stats2[2] = {nullptr, nullptr};   // ticket-merge outputs by solve parity
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
+    bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
     bool ticket_mode = false;        // one launch per solve: ticket merge by the last workgroup + the previous tail as aux
                                      // workgroup (sampled-slip kernel; deterministic kernel at K > 2048)
@@ -264,7 +266,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     alloc(&h->d_goal, B * 2 * 4);
     alloc(&h->d_mean, B * T * 2 * 4);
     alloc(&h->d_X, B * (T + 1) * 3 * (size_t)p.Kp * 4);
-    if (p.store_u) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
+    // the throughput kernel keeps its controls in this buffer instead of an LDS tile, requested or not
+    const bool want_wave = !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_ROLE_KERNEL | BN_FLAG_SAMPLED_SLIP)) && p.nblk <= 32 &&
+                           ((cfg->flags & BN_FLAG_WAVE_KERNEL) || (size_t)p.B * (p.nblk + 1) > kWaveKernelMinWorkgroups);
+    if (p.store_u || want_wave) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
     for (int q = 0; q < 2; ++q) {
         alloc(&h->d_cost[q], B * K * 4);
         alloc(&h->d_part[q], B * (size_t)p.nblk * (2 + 2 * T) * 4);
@@ -297,6 +302,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     // every rollout workgroup re-merges the previous solve's nblk partials: only worth it while they are few
     p.slip_on = (cfg->flags & BN_FLAG_SAMPLED_SLIP) ? 1 : 0;
     h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 32 && !p.slip_on;
+    // throughput kernel: launches with more workgroups than the role kernel keeps resident in one round (4 per CU)
+    h->wave_kernel = h->pipelined && want_wave;
     if (p.slip_on) {
         BN_HIP(hipMalloc((void **)&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4));
         BN_HIP(hipMemset(h->d_slip_std, 0, (size_t)h->n_maps * p.G * p.G * 4));
@@ -519,6 +526,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             p.env_z = (h->ep_z && h->ep_len > 0) ? h->ep_z + (size_t)(h->ep_len - 1) * p.B : nullptr;
             h->ep_len += 1;
         }
+        p.wave_kernel = (h->wave_kernel && !h->in_episode) ? 1 : 0;
         BN_HIP(bn::launch_rollout(p, mode, h->stream));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
@@ -811,7 +819,7 @@ int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host)
 {
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
-    if (!h->d_U) return fail(BN_ERR_STATE, "controls are only stored with BN_FLAG_STORE_CONTROLS");
+    if (!h->d_U || !h->p.store_u) return fail(BN_ERR_STATE, "controls are only stored with BN_FLAG_STORE_CONTROLS");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
     const size_t K = h->p.K, Kp = h->p.Kp, T = h->p.T, n = K * T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
@@ -962,7 +970,7 @@ int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise)
                     + 4 * K              // weights write
                     + 8 * T + 12 * (T + 1);   // U*, X* write
     if (noise != BN_NOISE_PHILOX) bytes += 8 * K * T;   // injected noise read
-    if (h->d_U) bytes += 8 * K * T;                     // _perturbed_action_seqs write
+    if (h->p.store_u) bytes += 8 * K * T;               // _perturbed_action_seqs write
     return bytes;
 }
 

@@ -25,6 +25,7 @@ struct SolveParams {
     int map_stride;      // G*G if every instance has its own map, 0 if shared
     int pow2;            // resolution is a power of two
     int store_u;
+    int wave_kernel;     // launch the one-wave-per-64-rollouts throughput variant (many workgroups per launch)
     int k0;              // global index of this handle's rollout 0 (K-sharded solve: rank r owns rollouts [k0, k0 + K)); keys the Philox stream
     float res, inv_res;
     float x0, y0;        // index origin == lower clamp (reference grid_map.py:199-201, robot_model.py:93-94)
@@ -84,6 +85,7 @@ struct SolveParams {
 
 size_t rollout_lds_bytes(const SolveParams &p);
 size_t finish_lds_bytes(const SolveParams &p);
+size_t wave_lds_bytes(const SolveParams &p);
 int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer for the headline rollout kernel (diagnostics)
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);

@@ -31,7 +31,7 @@ class NativeMPPI:
                  sigmas=(0.5, 0.5), inv_var=None, lambda_: float = 0.5, u_min=(0.0, -1.0), u_max=(1.0, 1.0),
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
-                 profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False):
+                 profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False, kernel: str = "auto"):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -58,7 +58,8 @@ class NativeMPPI:
                      | (_capi.BN_FLAG_PROFILE if profile else 0)
                      | (_capi.BN_FLAG_PRIVATE_STREAM if stream is None else 0)
                      | (0 if pipeline else _capi.BN_FLAG_NO_PIPELINE)
-                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0))
+                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0)
+                     | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
         self.store_controls = store_controls

@@ -72,6 +72,8 @@ enum {
     BN_FLAG_PROFILE = 1u << 3,         /* record HIP events around each kernel (see bn_mppi_kernel_ms) */
     BN_FLAG_PRIVATE_STREAM = 1u << 4,  /* ignore `stream`: the library creates and owns a non-blocking stream */
     BN_FLAG_NO_PIPELINE = 1u << 5,     /* always two launches per solve (rollout, finish); see bn_mppi_solve_async */
+    BN_FLAG_WAVE_KERNEL = 1u << 7,     /* always use the one-wave-per-64-rollouts throughput kernel (default: chosen by launch size) */
+    BN_FLAG_ROLE_KERNEL = 1u << 8,     /* always use the five-wave role-split latency kernel */
     BN_FLAG_SAMPLED_SLIP = 1u << 6     /* BASELINE config 3: every traversability lookup of the rollouts draws
                                           slip ~ Normal(map, slip_std)[cell]; see bn_mppi_set_slip_std */
 };

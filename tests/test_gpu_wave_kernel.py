@@ -1,0 +1,62 @@
+"""GPU: the one-wave-per-64-rollouts throughput kernel against the five-wave role kernel and the oracle.
+Same device functions in the same order per rollout: every output must be bit-identical."""
+import numpy as np
+import pytest
+
+from helpers import assert_oracle_parity, native_outputs, oracle_metrics
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K,T,B,noise", [(1024, 50, 3, "philox"), (1000, 33, 2, "kt2"), (2048, 50, 1, "t2k"), (130, 7, 5, "philox"), (64, 1, 1, "kt2")],
+                         ids=["c2-B3", "ragged-kt2", "K2048-t2k", "small-B5", "T1"])
+def test_wave_kernel_chain_equals_role_kernel_chain(K, T, B, noise):
+    import torch
+    from benchnav_amd import NativeMPPI, _capi, synth
+    from benchnav_amd.mppi import _DevArray
+    G, n = 256, 5
+    insts = [synth.make_instance(G, seed=20 + b, jitter=True) for b in range(B)]
+    rng = np.random.default_rng(2)
+    eps = rng.standard_normal((n, B, K, T, 2)).astype(np.float32)
+    st = torch.stack([it.start for it in insts]).cuda()
+    if noise == "kt2":
+        ed, kind = torch.from_numpy(eps).cuda(), _capi.BN_NOISE_DEVICE_KT2
+    elif noise == "t2k":
+        ed, kind = torch.from_numpy(np.ascontiguousarray(eps.transpose(0, 1, 3, 4, 2))).cuda(), _capi.BN_NOISE_DEVICE_T2K
+    else:
+        ed, kind = None, _capi.BN_NOISE_PHILOX
+    torch.cuda.synchronize()
+    res = {}
+    for kern in ("role", "wave"):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, seed=9, store_controls=True, kernel=kern) as pl:
+            for b, it in enumerate(insts):
+                pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
+            if ed is None:
+                pl.solve_n_async_device(n, st.data_ptr())
+            else:
+                pl.solve_n_async_device(n, st.data_ptr(), ed.data_ptr(), kind, n, eps[0].size)
+            pl.sync()
+            xs = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_XSTAR)[0], (B, T + 1, 3)), device="cuda").cpu().numpy()
+            res[kern] = [(pl.states(b), pl.controls(b), pl.costs(b), pl.weights(b), pl.get_mean(b), xs[b].copy()) for b in range(B)]
+    for b in range(B):
+        for j, (a_, b_) in enumerate(zip(res["wave"][b], res["role"][b])):
+            assert np.array_equal(a_, b_), (b, j)
+
+
+def test_wave_kernel_matches_oracle_and_is_the_default_for_large_batches():
+    from oracle import oracle as O
+    from benchnav_amd import NativeMPPI, synth
+    K, T, G, B = 1024, 50, 256, 96                      # 96 x 17 workgroups > 1536: auto-selects the throughput kernel
+    insts = [synth.make_instance(G, seed=s, jitter=True) for s in range(B)]
+    rng = np.random.default_rng(5)
+    eps = rng.standard_normal((B, K, T, 2)).astype(np.float32)
+    mean = np.clip(rng.standard_normal((T, 2)) * 0.2 + [0.6, 0.0], [0, -1], [1, 1]).astype(np.float32)
+    states = np.stack([it.start.numpy() for it in insts])
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, store_controls=True) as pl:
+        for b, it in enumerate(insts):
+            pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b); pl.set_mean(mean, b)
+        us, xs = pl.solve(states, eps)
+        for b in (0, 31, 95):
+            p = O.make_params(K, T, G, 0.5, insts[b].goal.numpy(), trig=O.TRIG_SPEC)
+            orc = O.solve(p, insts[b].risk.numpy(), states[b], mean, eps[b])
+            assert_oracle_parity(oracle_metrics(native_outputs(pl, us, xs, b), orc), ctx=f"instance {b}")

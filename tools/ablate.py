@@ -3,18 +3,23 @@ Run on the GPU box:  python tools/ablate.py   (builds were made beforehand by `p
 import os, sys, subprocess, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-MASKS = {0: "full", 1: "-stagecost", 2: "-fp64acc", 4: "-Xstores", 8: "-Utile/ctrlcost", 16: "-sincos", 32: "-gather", 64: "-wrap",
+MASKS = {0: "full", 1: "-stagecost", 4: "-Xstores", 8: "-Utile/ctrlcost", 16: "-sincos", 32: "-gather",
          1 | 2 | 4 | 8: "chain only", 127: "everything off"}
 VAR_DIR = os.path.join(ROOT, "tools", "_ablate")
 
 def build():
     from benchnav_amd import build as b
     os.makedirs(VAR_DIR, exist_ok=True)
+    procs = []
     for m in MASKS:
         out = os.path.join(VAR_DIR, f"lib_{m}.so")
         cmd = [b.hipcc(), *b.HIPCC_FLAGS, f"-DBN_ABLATE={m}", "-x", "hip", *[os.path.join(b.CSRC, s) for s in b.SOURCES], "-o", out]
-        subprocess.check_call(cmd)
-        print("built", out)
+        procs.append((out, subprocess.Popen(cmd)))
+        if len(procs) % 4 == 0:
+            for o, pr in procs[-4:]:
+                pr.wait(); print("built", o, pr.returncode)
+    for o, pr in procs:
+        pr.wait()
 
 def run_one(mask):
     import ctypes, numpy as np, torch
@@ -23,10 +28,11 @@ def run_one(mask):
     from benchnav_amd import NativeMPPI, synth
     inst = synth.make_instance(256, seed=0)
     res = []
+    B = int(os.environ.get("BN_ABLATE_B", "1"))          # instances per launch: 1 = latency regime, 60 = one full resident round
     for noise in ("philox", "t2k"):
-        pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, profile=True, stream=0)
+        pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, profile=True, stream=0, num_instances=B, shared_map=True)
         pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
-        st = inst.start.cuda(); eps = torch.randn(50, 2, 1024, device="cuda"); torch.cuda.synchronize()
+        st = torch.stack([inst.start] * B).cuda(); eps = torch.randn(B, 50, 2, 1024, device="cuda"); torch.cuda.synchronize()
         for it in range(2):
             for _ in range(300):
                 if noise == "philox": pl.solve_async_device(st.data_ptr())

@@ -16,9 +16,9 @@ int main()
     float *out; hipMalloc(&out, 1 << 20);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipFuncSetAttribute((const void *)spin, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    struct Cfg { int threads; int lds; } cfgs[] = {{320, 39552}, {320, 0}, {64, 0}, {64, 39552}, {256, 39552}, {256, 0}, {1024, 0}, {640, 79104}, {320, 16384}, {320, 65536}};
+    struct Cfg { int threads; int lds; } cfgs[] = {{64, 3400}, {320, 39552}, {320, 0}, {64, 0}, {64, 39552}, {256, 39552}, {256, 0}, {1024, 0}, {640, 79104}, {320, 16384}, {320, 65536}};
     for (auto c : cfgs)
-        for (int n : {256, 1024, 2048}) {
+        for (int n : {1024, 4352, 6144, 8192}) {
             float best = 1e9f;
             for (int rep = 0; rep < 5; ++rep) {
                 hipEventRecord(e0, 0);
