@@ -51,9 +51,10 @@ class MPPI(nn.Module):
     """Model Predictive Path Integral control on one MI355X.
 
     Extra keyword arguments (not in the reference):
-      noise  "torch"  (default) draw eps with torch's CPU generator exactly like the reference
-                      does on CPU (bit-identical stream for the same seed), upload it;
-             "torch_device"  draw eps with torch's generator on the planner's device;
+      noise  "torch_device"  (default) draw eps with torch's generator on the planner's device, as the
+                      reference does when it runs on a GPU (seeded by torch.manual_seed(seed));
+             "torch"  draw eps with torch's CPU generator exactly like the reference does on CPU
+                      (bit-identical stream for the same seed: what the golden fixtures hold), upload it;
              "philox"        generate eps inside the rollout kernel (fastest).
       store_controls  keep `_perturbed_action_seqs` in HBM (the reference always has it).
       copy_outputs    return fresh tensors from forward() like the reference; False returns
@@ -62,7 +63,7 @@ class MPPI(nn.Module):
 
     def __init__(self, horizon: int, num_samples: int, dim_state: int, dim_control: int, dynamics, objectives,
                  sigmas: torch.Tensor, lambda_: float, device=torch.device("cuda"), dtype=torch.float32,
-                 seed: int = 42, *, noise: str = "torch", store_controls: bool = True,
+                 seed: int = 42, *, noise: str = "torch_device", store_controls: bool = True,
                  copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1) -> None:
         super().__init__()
         torch.manual_seed(seed)                                    # mppi.py:55
@@ -141,13 +142,13 @@ class MPPI(nn.Module):
         self._buf_xstar = self._wrap(_capi.BN_BUF_XSTAR, (1, T + 1, 3))
         self._buf_mean = self._wrap(_capi.BN_BUF_MEAN, (T, 2))
         self._eps_dev: Optional[torch.Tensor] = None
-        self._action_noises: Optional[torch.Tensor] = None
+        self._noise_cache: Optional[torch.Tensor] = None
 
         if noise == "torch":
             # the reference constructor consumes one (K,T,2) draw of the global CPU stream (mppi.py:105-107)
-            self._action_noises = torch.empty(K, T, 2).normal_() * s_cpu
+            self._noise_cache = torch.empty(K, T, 2).normal_() * s_cpu
         elif noise == "torch_device":
-            self._action_noises = torch.randn(K, T, 2, device=dev) * self._sigmas
+            self._noise_cache = torch.randn(K, T, 2, device=dev) * self._sigmas
 
     # -- plumbing ------------------------------------------------------------------
     def _wrap(self, buf_id, shape):
@@ -232,7 +233,7 @@ class MPPI(nn.Module):
         else:
             self._eps_dev = None
             kind, eptr = _capi.BN_NOISE_PHILOX, C.c_void_p(None)
-        self._action_noises = None if self._eps_dev is None else self._eps_dev * self._sigmas
+        self._noise_cache = None                                       # _action_noises is derived on demand
         self._last_state = st                                          # keep alive until the kernels ran
         _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
                                                   eptr, kind))
@@ -243,12 +244,20 @@ class MPPI(nn.Module):
 
     solve = forward
 
+    @property
+    def _action_noises(self) -> Optional[torch.Tensor]:
+        """The reference's `_action_noises` (eps * sigma, mppi.py:149-151) of the latest forward(); None with
+        in-kernel noise.  Derived on demand: the planner consumes eps itself."""
+        if self._noise_cache is None and self._eps_dev is not None:
+            self._noise_cache = self._eps_dev * self._sigmas
+        return self._noise_cache
+
     def solve_with_noise(self, state: torch.Tensor, eps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """forward() with caller-supplied standard-normal noise eps (K,T,2) (teacher-forced parity tests)."""
         assert eps.shape == (self._num_samples, self._horizon, 2)
         st = torch.as_tensor(state).detach().to(self._device, self._dtype).contiguous()
         self._eps_dev = eps.detach().to(self._device, self._dtype).contiguous()
-        self._action_noises = self._eps_dev * self._sigmas
+        self._noise_cache = None
         self._last_state = st
         _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
                                                   C.c_void_p(self._eps_dev.data_ptr()), _capi.BN_NOISE_DEVICE_KT2))
