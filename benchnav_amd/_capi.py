@@ -61,6 +61,8 @@ SYMBOLS = {
     "bn_mppi_shard_partials": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bn_mppi_shard_finish_async": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "bn_mppi_env_attach": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint64]),
+    "bn_mppi_env_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bn_mppi_env_collision_check": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p]),
     "bn_mppi_episode_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_void_p]),
     "bn_mppi_episode_log": (C.c_int, [_H, _FP, _FP, _FP, C.POINTER(C.c_int32)]),
     "bn_mppi_dwa_solve": (C.c_int, [_H, _FP, _FP, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(C.c_int32)]),

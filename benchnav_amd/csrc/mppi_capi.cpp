@@ -639,7 +639,6 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
                        float goal_threshold, float delta_t, uint64_t seed)
 {
     if (!h || !latent_mean || !latent_std) return fail(BN_ERR_INVALID, "null argument");
-    if (!h->pipelined) return fail(BN_ERR_INVALID, "the device-side closed loop needs the pipelined mode (num_samples <= 2048)");
     if (!(goal_threshold >= 0.0f) || !(delta_t > 0.0f)) return fail(BN_ERR_INVALID, "goal_threshold >= 0 and delta_t > 0 required");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
     if (int rc = flush_tail(h)) return rc;
@@ -660,11 +659,33 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
     return BN_OK;
 }
 
+int bn_mppi_env_step(bn_mppi_t *h, const float *actions_device, float *states_device, float *rewards_device,
+                     int32_t *terminated_device, const float *z_device, uint64_t step_index)
+{
+    if (!h || !actions_device || !states_device || !rewards_device || !terminated_device) return fail(BN_ERR_INVALID, "null argument");
+    if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_step");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(bn::launch_env_step(h->p, actions_device, states_device, rewards_device, terminated_device, z_device, step_index, h->stream));
+    return BN_OK;
+}
+
+int bn_mppi_env_collision_check(bn_mppi_t *h, const float *states_device, int32_t n_positions, float stuck_threshold,
+                                const float *z_device, uint64_t draw_index, uint8_t *out_device)
+{
+    if (!h || !states_device || !out_device) return fail(BN_ERR_INVALID, "null argument");
+    if (n_positions < 1) return fail(BN_ERR_INVALID, "n_positions must be >= 1");
+    if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_collision_check");
+    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_HIP(bn::launch_env_collision(h->p, states_device, n_positions, stuck_threshold, z_device, draw_index, out_device, h->stream));
+    return BN_OK;
+}
+
 int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, bn_mem_kind states_where, const float *eps,
                           bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride, const float *z_device)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_episode_async");
+    if (!h->pipelined) return fail(BN_ERR_INVALID, "the device-side closed loop needs the pipelined mode (num_samples <= 2048)");
     if (n_steps < 1) return fail(BN_ERR_INVALID, "n_steps must be >= 1");
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
     if (int rc = flush_tail(h)) return rc;            // anything pending belongs to the pre-episode state

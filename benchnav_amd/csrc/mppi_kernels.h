@@ -95,6 +95,11 @@ bool sampled_fused(const SolveParams &p);   // the sampled launch merges by tick
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
                       float *w, int *best, hipStream_t s);
 
+hipError_t launch_env_step(const SolveParams &p, const float *actions, float *states, float *reward, int *terminated, const float *z,
+                           uint64_t step, hipStream_t s);
+hipError_t launch_env_collision(const SolveParams &p, const float *states, int N, float thr, const float *z, uint64_t draw,
+                                unsigned char *out, hipStream_t s);
+
 // layout conversion helpers (planner-native k-fastest <-> reference k-major)
 hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s);   // (T1,3,Kp)->(K,T1,3)
 hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int Kp, int T, hipStream_t s);  // (T,2,Kp)->(K,T,2)

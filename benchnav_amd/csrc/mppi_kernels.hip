@@ -1518,6 +1518,50 @@ __global__ void philox_slip_kernel(float *__restrict__ zt, float *__restrict__ z
         }
 }
 
+// ------------------------------------------------------------------------------
+// PlanetaryEnv mirror for B environments ("next" row N2): step (planetary_env.py:189-219) and collision_check
+// (planetary_env.py:221-232) as stand-alone calls, for callers that drive the loop themselves; the fused episode of
+// the pipelined solve uses the same env_advance.
+// ------------------------------------------------------------------------------
+template <int GEO>
+__global__ void env_step_kernel(const SolveParams p, const float *__restrict__ actions, float *states, float *reward,
+                                int *terminated, const float *z, uint64_t step)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    const EnvStep e = env_advance<GEO>(p, b, states[b * 3 + 0], states[b * 3 + 1], states[b * 3 + 2], actions[b * 2 + 0],
+                                       actions[b * 2 + 1], z, step);
+    states[b * 3 + 0] = e.x; states[b * 3 + 1] = e.y; states[b * 3 + 2] = e.th;
+    reward[b] = e.reward;
+    terminated[b] = e.reached ? 1 : 0;
+}
+
+// is_collisions[b, n] = (1 - clamp(Normal(mean, std)[cell(states[b, n])].sample(), 0, 1)) <= stuck_threshold: one fresh
+// slip draw per position, like the observation-mode get_traversability the reference calls here.
+template <int GEO>
+__global__ void env_collision_kernel(const SolveParams p, const float *__restrict__ states, int N, float thr,
+                                     const float *__restrict__ z, uint64_t draw, unsigned char *out)
+{
+    const size_t tot = (size_t)p.B * N;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / N);
+        const int ix = clampi(raw_cell<GEO>(states[i * 3 + 0], p.x0, p.res, p.inv_res), 0, p.G - 1);
+        const int iy = clampi(raw_cell<GEO>(states[i * 3 + 1], p.y0, p.res, p.inv_res), 0, p.G - 1);
+        const size_t cell = (size_t)b * p.map_stride + (size_t)iy * p.G + ix;
+        float zz;
+        if (z) {
+            zz = z[i];
+        } else {
+            const u32x4 q = philox4x32_10(u32x4{(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)draw, 0x434f4c4cu ^ (uint32_t)(draw >> 32)},
+                                          (uint32_t)p.env_seed, (uint32_t)(p.env_seed >> 32));
+            float z1;
+            box_muller(q.x, q.y, zz, z1);
+        }
+        const float slip = zz * p.lat_std[cell] + p.lat_mean[cell];
+        out[i] = (1.0f - clampf(slip, 0.0f, 1.0f)) <= thr ? 1 : 0;
+    }
+}
+
 // ---- layout helpers -----------------------------------------------------------
 __global__ void soa_to_aos_kernel(const float *__restrict__ in, float *__restrict__ out, int K, int Kp, int R)
 {   // in (R, Kp pitch) -> out (K, R)
@@ -1744,6 +1788,30 @@ hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *s
     default: BN_DWA_LAUNCH(kGeoGeneral); break;
     }
 #undef BN_DWA_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_env_step(const SolveParams &p, const float *actions, float *states, float *reward, int *terminated, const float *z,
+                           uint64_t step, hipStream_t s)
+{
+    const dim3 grid((p.B + 63) / 64), block(64);
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: env_step_kernel<kGeoPow2Origin0><<<grid, block, 0, s>>>(p, actions, states, reward, terminated, z, step); break;
+    case kGeoPow2: env_step_kernel<kGeoPow2><<<grid, block, 0, s>>>(p, actions, states, reward, terminated, z, step); break;
+    default: env_step_kernel<kGeoGeneral><<<grid, block, 0, s>>>(p, actions, states, reward, terminated, z, step); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_env_collision(const SolveParams &p, const float *states, int N, float thr, const float *z, uint64_t draw,
+                                unsigned char *out, hipStream_t s)
+{
+    const dim3 grid = grid_for((size_t)p.B * N);
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: env_collision_kernel<kGeoPow2Origin0><<<grid, 256, 0, s>>>(p, states, N, thr, z, draw, out); break;
+    case kGeoPow2: env_collision_kernel<kGeoPow2><<<grid, 256, 0, s>>>(p, states, N, thr, z, draw, out); break;
+    default: env_collision_kernel<kGeoGeneral><<<grid, 256, 0, s>>>(p, states, N, thr, z, draw, out); break;
+    }
     return hipGetLastError();
 }
 

@@ -197,6 +197,18 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
  */
 int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *latent_std, bn_mem_kind where,
                        float goal_threshold, float delta_t, uint64_t seed);
+/* The two PlanetaryEnv calls on their own, for callers that drive the loop themselves (all pointers device memory, stream-ordered):
+ *   env_step             planetary_env.py:189-219 for the B environments: states (B,3) advance in place through the
+ *                        observation-mode transit with actions (B,2); rewards (B,) = the sampled traversability;
+ *                        terminated (B,) = within goal_threshold of the goal.  An environment that had already
+ *                        terminated stays where it is.  z (B,) injects the slip draws, NULL = Philox keyed by
+ *                        (env seed, step_index).
+ *   env_collision_check  planetary_env.py:221-232: out (B,N) = sampled traversability at states (B,N,3) <= stuck_threshold,
+ *                        one fresh draw per position (z (B,N) injects them; NULL = Philox keyed by (env seed, draw_index)). */
+int bn_mppi_env_step(bn_mppi_t *h, const float *actions_device, float *states_device, float *rewards_device,
+                     int32_t *terminated_device, const float *z_device, uint64_t step_index);
+int bn_mppi_env_collision_check(bn_mppi_t *h, const float *states_device, int32_t n_positions, float stuck_threshold,
+                                const float *z_device, uint64_t draw_index, uint8_t *out_device);
 int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride,
                           const float *z_device);
