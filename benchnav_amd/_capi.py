@@ -82,6 +82,7 @@ SYMBOLS = {
     "bn_risk_map_infer": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_float,
                                     C.c_int32, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]),
     "bn_risk_last_error": (C.c_char_p, []),
+    "bn_device_math_eval": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bn_last_error": (C.c_char_p, []),
     "bn_mppi_abi_version": (C.c_int, []),
 }

@@ -79,6 +79,13 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
     return __builtin_amdgcn_fmed3f(v, lo, hi);
 }
 
+// Correctly rounded sqrt (== sqrtf of the oracle's libm): the compiler's IEEE expansion of sqrtf under -fno-fast-math
+// (v_sqrt_f32 + two fma residuals that pick the correctly rounded neighbour, 2^32 scaling for inputs v_sqrt_f32 would
+// flush).  A hand-written form of the same fix-up was measured at the same speed (selects) or slower (a branch for the
+// tiny inputs splits the consumer's four-step block), so the compiler's stays.  tests/test_gpu_device_math.py checks it
+// value by value against IEEE sqrt, denormals included.
+__device__ __forceinline__ float sqrt_cr(float x) { return sqrtf(x); }
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
 {
     return min(max(v, lo), hi);

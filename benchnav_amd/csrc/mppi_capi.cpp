@@ -1001,6 +1001,14 @@ int bn_mppi_debug_blocks_per_cu(bn_mppi_t *h) { return bn::rollout_blocks_per_cu
 void bn_mppi_debug_set_stamps(bn_mppi_t *h, void *device_ptr) { h->p.stamps = (unsigned long long *)device_ptr; }
 #endif
 
+int bn_device_math_eval(int32_t fn, const float *in_device, float *out_device, int64_t n, void *stream)
+{
+    if (fn < 0 || fn > 4 || !in_device || !out_device || n < 0) return fail(BN_ERR_INVALID, "bad argument");
+    if (n == 0) return BN_OK;
+    BN_HIP(bn::launch_math_eval(fn, in_device, out_device, (size_t)n, (hipStream_t)stream));
+    return BN_OK;
+}
+
 const char *bn_last_error(void) { return g_last_error.c_str(); }
 int bn_mppi_abi_version(void) { return BN_MPPI_ABI_VERSION; }
 

@@ -100,6 +100,8 @@ hipError_t launch_env_step(const SolveParams &p, const float *actions, float *st
 hipError_t launch_env_collision(const SolveParams &p, const float *states, int N, float thr, const float *z, uint64_t draw,
                                 unsigned char *out, hipStream_t s);
 
+hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipStream_t s);   // 0 sqrt, 1 sin, 2 cos, 3 wrap, 4 wrap_near
+
 // layout conversion helpers (planner-native k-fastest <-> reference k-major)
 hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s);   // (T1,3,Kp)->(K,T1,3)
 hipError_t launch_controls_to_reference(const float *U_soa, float *U_aos, int K, int Kp, int T, hipStream_t s);  // (T,2,Kp)->(K,T,2)

@@ -186,7 +186,7 @@ __device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, floa
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
     EnvStep r;
     const float d0x = sx - gx, d0y = sy - gy;
-    r.frozen = sqrtf(d0x * d0x + d0y * d0y) < p.goal_thr;          // terminated at an earlier step
+    r.frozen = sqrt_cr(d0x * d0x + d0y * d0y) < p.goal_thr;          // terminated at an earlier step
     const int ix = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
     const int iy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
     const size_t cell = (size_t)b * p.map_stride + (size_t)iy * p.G + ix;
@@ -212,7 +212,7 @@ __device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, floa
     r.th = r.frozen ? sth : wrap_angle(tn);
     r.reward = trav;
     const float dx = r.x - gx, dy = r.y - gy;
-    r.reached = sqrtf(dx * dx + dy * dy) < p.goal_thr;             // planetary_env.py:215-217
+    r.reached = sqrt_cr(dx * dx + dy * dy) < p.goal_thr;             // planetary_env.py:215-217
     return r;
 }
 
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     do {                                                                                                       \
         if (BN_ABLATE & 1) { BN_KEEP(o.x); BN_KEEP(o.y); BN_KEEP(o.w); } else {                                \
         const float dx = o.x - gx, dy = o.y - gy;                                                              \
-        const float sc = sqrtf(dx * dx + dy * dy) + (o.w <= p.thr ? 1.0e4f : 0.0f);   /* objectives.py:47-53 */ \
+        const float sc = sqrt_cr(dx * dx + dy * dy) + (o.w <= p.thr ? 1.0e4f : 0.0f);   /* objectives.py:47-53 */ \
         Sd += (double)sc;                                                                                      \
         }                                                                                                      \
     } while (0)
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     } else if (wv == 4) {
         const float xT = fin[lane], yT = fin[64 + lane], trT = fin[192 + lane], A = fin[256 + lane];
         const float dxT = xT - gx, dyT = yT - gy;
-        const float term = sqrtf(dxT * dxT + dyT * dyT) + (trT <= p.thr ? 1.0e4f : 0.0f);    // mppi.py:184
+        const float term = sqrt_cr(dxT * dxT + dyT * dyT) + (trT <= p.thr ? 1.0e4f : 0.0f);    // mppi.py:184
         const float cost = ((float)Sd + term) + A;                                             // mppi.py:186-190
         if (active) p.cost[(size_t)b * K + k] = cost;
         // block-local softmin statistics   mppi.py:193-199
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
         float *Xt = Xb + (size_t)(3 * (t)) * Kp;                                                                  \
         Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                                 \
         const float dx = xn - gx, dy = yn - gy;                                                                   \
-        Sd += (double)(sqrtf(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));   /* objectives.py:47-53 */  \
+        Sd += (double)(sqrt_cr(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));   /* objectives.py:47-53 */  \
         Ad += (double)(p.lambda_ * (mv[2 * (t)] * (u0) + mv[2 * (t) + 1] * (u1)));      /* mppi.py:178-182 */      \
     } while (0)
     for (int t = 0; t < T; t += 2) {
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
         Xt[0] = c.x; Xt[Kp] = c.y; Xt[2 * Kp] = c.th;
     }
     const float dxT = c.x - gx, dyT = c.y - gy;
-    const float term = sqrtf(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);      // mppi.py:184
+    const float term = sqrt_cr(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);      // mppi.py:184
     const float cost = ((float)Sd + term) + (float)Ad;                                          // mppi.py:186-190
     if (active) p.cost[(size_t)b * K + k] = cost;
     const float z = active ? (-cost) / p.lambda_ : -INFINITY;
@@ -1199,11 +1199,11 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
         else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, u0, u1, xn, yn, tn);
         if (Xk && active) { Xk[3 * t] = xn; Xk[3 * t + 1] = yn; Xk[3 * t + 2] = tn; }
         const float dx = xn - hx, dy = yn - hy;
-        cost = cost + (sqrtf(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));      // objectives.py:47-53
+        cost = cost + (sqrt_cr(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));      // objectives.py:47-53
     }
     if (Xk && active) { Xk[3 * T] = c.x; Xk[3 * T + 1] = c.y; Xk[3 * T + 2] = c.th; }
     const float dxT = c.x - gx, dyT = c.y - gy;
-    cost = cost + (sqrtf(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f));       // dwa.py:256
+    cost = cost + (sqrt_cr(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f));       // dwa.py:256
     if (active) cost_out[(size_t)b * NA + tid] = cost;
 
     // argmin with first-index tie break, then softmax(-cost)
@@ -1375,7 +1375,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         const float2 ms = win2[__float_as_int(o.w)];
         const float tc = trav_from_slip(ms.x, ms.y, Zc[t * 64 + lane]);                // objectives.py:50
         const float dx = o.x - gx, dy = o.y - gy;
-        Zc[t * 64 + lane] = sqrtf(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f);  // objectives.py:46-53
+        Zc[t * 64 + lane] = sqrt_cr(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f);  // objectives.py:46-53
     }
     __syncthreads();
     BN_STAMP(3);
@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         const int ec = slip_cell_safe<GEO, false>(p, w, xn, yn);
         const float tc = trav_from_slip(mu[ec], sg[ec], zq[2 + (t & 1)]);
         const float dx = xn - gx, dy = yn - gy;
-        Sd += (double)(sqrtf(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f));
+        Sd += (double)(sqrt_cr(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f));
         Ad += (double)(p.lambda_ * (mv[2 * t] * u0 + mv[2 * t + 1] * u1));
     }
     {
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
     const int eT = slip_cell_safe<GEO, false>(p, w, x, y);
     const float tT = trav_from_slip(mu[eT], sg[eT], zq[2 + (T & 1)]);
     const float dxT = x - gx, dyT = y - gy;
-    const float term = sqrtf(dxT * dxT + dyT * dyT) + (tT <= p.thr ? 1.0e4f : 0.0f);
+    const float term = sqrt_cr(dxT * dxT + dyT * dyT) + (tT <= p.thr ? 1.0e4f : 0.0f);
     const float cost = ((float)Sd + term) + (float)Ad;
     if (active) p.cost[(size_t)b * K + k] = cost;
     const float zz = active ? (-cost) / p.lambda_ : -INFINITY;
@@ -1559,6 +1559,23 @@ __global__ void env_collision_kernel(const SolveParams p, const float *__restric
         }
         const float slip = zz * p.lat_std[cell] + p.lat_mean[cell];
         out[i] = (1.0f - clampf(slip, 0.0f, 1.0f)) <= thr ? 1 : 0;
+    }
+}
+
+// ---- the library's device math on caller-supplied inputs (test hook: bn_device_math_eval) ----
+__global__ void math_eval_kernel(int fn, const float *__restrict__ in, float *__restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = in[i];
+        float sn, cs, r;
+        switch (fn) {
+        case 0: r = sqrt_cr(x); break;
+        case 1: sincos_spec(x, sn, cs); r = sn; break;
+        case 2: sincos_spec(x, sn, cs); r = cs; break;
+        case 3: r = wrap_angle(x); break;
+        default: r = wrap_angle_near(x); break;
+        }
+        out[i] = r;
     }
 }
 
@@ -1812,6 +1829,12 @@ hipError_t launch_env_collision(const SolveParams &p, const float *states, int N
     case kGeoPow2: env_collision_kernel<kGeoPow2><<<grid, 256, 0, s>>>(p, states, N, thr, z, draw, out); break;
     default: env_collision_kernel<kGeoGeneral><<<grid, 256, 0, s>>>(p, states, N, thr, z, draw, out); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipStream_t s)
+{
+    math_eval_kernel<<<grid_for(n), 256, 0, s>>>(fn, in, out, n);
     return hipGetLastError();
 }
 

@@ -290,6 +290,12 @@ int bn_risk_map_infer(int32_t device_id, void *stream, const float *mean, const 
                       const float *z, bn_mem_kind where_z, uint64_t seed, float *out, bn_mem_kind where_out);
 const char *bn_risk_last_error(void);
 
+/* Test hook: the library's device arithmetic (DESIGN.md "Arithmetic spec") applied elementwise to n device floats:
+ * fn 0 = correctly rounded sqrt, 1 / 2 = sin / cos of the spec, 3 = heading wrap (theta + pi) % 2pi - pi with
+ * torch.remainder semantics (robot_model.py:90), 4 = its in-loop form.  Lets the tests compare the kernels' building
+ * blocks with the oracle's one value at a time. */
+int bn_device_math_eval(int32_t fn, const float *in_device, float *out_device, int64_t n, void *stream);
+
 const char *bn_last_error(void);
 int bn_mppi_abi_version(void);
 
