@@ -883,12 +883,15 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
         if (wv == 0) {                                                                                         \
             if ((cc) * TU < T) {                                                                               \
                 float *slot = ring + (((cc) & 1) * TU) * 256;                                                  \
-                float uc[TU][2];                                                                               \
+                /* the NEXT chunk's controls (produced last phase, visible since the barrier) are read now and */ \
+                /* land under this chunk's steps: no LDS round trip at the head of a phase                    */ \
+                float un[TU][2];                                                                               \
                 _Pragma("unroll") for (int i = 0; i < TU; ++i) {                                               \
-                    const int t = min((cc) * TU + i, T - 1);                                                   \
-                    uc[i][0] = Ul[(2 * t) * kUPad + lane];                                                     \
-                    uc[i][1] = Ul[(2 * t + 1) * kUPad + lane];                                                 \
+                    const int t = min(((cc) + 1) * TU + i, T - 1);                                             \
+                    un[i][0] = Ul[(2 * t) * kUPad + lane];                                                     \
+                    un[i][1] = Ul[(2 * t + 1) * kUPad + lane];                                                 \
                 }                                                                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                             \
                 _Pragma("unroll") for (int i = 0; i < TU; ++i) {                                               \
                     const int t = (cc) * TU + i;                                                               \
                     if (!(GUARD) || t < T) {                                                                   \
@@ -896,6 +899,7 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
                         else BN_CHAIN(false, i, slot + i * 256);                                               \
                     }                                                                                          \
                 }                                                                                              \
+                _Pragma("unroll") for (int i = 0; i < TU; ++i) { uc[i][0] = un[i][0]; uc[i][1] = un[i][1]; }   \
             }                                                                                                  \
         } else if (wv >= 3) {                                                                                  \
             if ((cc) >= 1) {                                                                                   \
@@ -920,6 +924,15 @@ __global__ __launch_bounds__(kRolloutThreads) void rollout_kernel(const SolvePar
     } while (0)
 
     const int nfull = T / TU;                         // chunks with all TU steps
+    float uc[TU][2];                                  // chain: the controls of its current chunk
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < TU; ++i) {
+            const int t = min(i, T - 1);
+            uc[i][0] = Ul[(2 * t) * kUPad + lane];
+            uc[i][1] = Ul[(2 * t + 1) * kUPad + lane];
+        }
+    }
     BN_PHASE(0, true, true);
     BN_BAR();
     BN_STAMP(2);
