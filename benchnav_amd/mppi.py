@@ -30,18 +30,26 @@ class _DevArray:
         }
 
 
-def _planner_inputs(dynamics, objectives):
+def _planner_inputs(dynamics, objectives, sampled_slip=False):
     """What the native planner reads from the reference-shaped `dynamics` / `objectives`
     objects: the risk map, the grid geometry, the action bounds, the goal
-    and the stuck threshold."""
+    and the stuck threshold.  With sampled_slip: the latent slip model instead of the risk map."""
     cfg = getattr(dynamics, "_model_config", None)
     mode = getattr(cfg, "mode", "inference")
-    if mode != "inference":
-        # the reference's transit returns a tuple in observation mode and MPPI.forward fails on it
-        raise TypeError("MPPI needs dynamics in 'inference' mode (got %r)" % (mode,))
     gm = dynamics._grid_map
-    risks = dynamics._traversability_model._risks
-    return dict(risks=risks, grid_size=int(gm.grid_size), resolution=float(gm.resolution),
+    slip_std = None
+    if sampled_slip:
+        if mode != "observation":
+            raise TypeError("sampled_slip=True plans with observation-mode dynamics (got mode %r)" % (mode,))
+        latent = gm.distributions["latent_models"]              # traversability_model.py:66-68
+        risks, slip_std = latent.mean, latent.stddev
+    else:
+        if mode != "inference":
+            # the reference's transit returns a tuple in observation mode and MPPI.forward fails on it
+            raise TypeError("MPPI needs dynamics in 'inference' mode (got %r); sampled_slip=True opts into planning "
+                            "with the sampled slip of observation mode" % (mode,))
+        risks = dynamics._traversability_model._risks
+    return dict(risks=risks, slip_std=slip_std, grid_size=int(gm.grid_size), resolution=float(gm.resolution),
                 x_limits=(float(gm.x_limits[0]), float(gm.x_limits[1])),
                 y_limits=(float(gm.y_limits[0]), float(gm.y_limits[1])),
                 goal=objectives._goal_pos, stuck_threshold=float(objectives._stuck_threshold))
@@ -56,6 +64,10 @@ class MPPI(nn.Module):
              "torch"  draw eps with torch's CPU generator exactly like the reference does on CPU
                       (bit-identical stream for the same seed: what the golden fixtures hold), upload it;
              "philox"        generate eps inside the rollout kernel (fastest).
+      sampled_slip    plan with observation-mode dynamics (BASELINE config 3): every traversability lookup of the
+                      rollouts draws slip ~ Normal(mean, std)[cell] from `grid_map.distributions["latent_models"]`
+                      (traversability_model.py:65-69).  The reference's own MPPI cannot (its transit returns a tuple
+                      there), so this is opt-in; without it observation-mode dynamics raise TypeError as in the reference.
       store_controls  keep `_perturbed_action_seqs` in HBM (the reference always has it).
       copy_outputs    return fresh tensors from forward() like the reference; False returns
                       views of the planner's buffers (overwritten by the next call).
@@ -64,7 +76,7 @@ class MPPI(nn.Module):
     def __init__(self, horizon: int, num_samples: int, dim_state: int, dim_control: int, dynamics, objectives,
                  sigmas: torch.Tensor, lambda_: float, device=torch.device("cuda"), dtype=torch.float32,
                  seed: int = 42, *, noise: str = "torch_device", store_controls: bool = True,
-                 copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1) -> None:
+                 copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1, sampled_slip: bool = False) -> None:
         super().__init__()
         torch.manual_seed(seed)                                    # mppi.py:55
 
@@ -106,7 +118,7 @@ class MPPI(nn.Module):
         self._inv_covariance = inv_cov.to(dev, dtype)
         self._sample_shape = torch.Size([num_samples, horizon])
 
-        inp = _planner_inputs(dynamics, objectives)
+        inp = _planner_inputs(dynamics, objectives, sampled_slip)
         lib = _capi.load()
         cfg = _capi.Config()
         lib.bn_mppi_config_init(C.byref(cfg))
@@ -121,7 +133,8 @@ class MPPI(nn.Module):
             cfg.u_min[i], cfg.u_max[i] = float(umin[i]), float(umax[i])
         cfg.lambda_, cfg.dt, cfg.stuck_threshold = lambda_, delta_t, inp["stuck_threshold"]
         cfg.seed = seed
-        cfg.flags = (_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0) | (_capi.BN_FLAG_PROFILE if profile else 0)
+        cfg.flags = ((_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0) | (_capi.BN_FLAG_PROFILE if profile else 0)
+                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0))
         with torch.cuda.device(dev):
             cfg.stream = torch.cuda.current_stream(dev).cuda_stream
             self._handle = C.c_void_p()
@@ -130,6 +143,11 @@ class MPPI(nn.Module):
         risks = inp["risks"].detach().to(torch.float32).contiguous()
         assert risks.shape == (inp["grid_size"], inp["grid_size"])
         self.set_risk_map(risks)
+        if sampled_slip:
+            std = inp["slip_std"].detach().to(torch.float32).contiguous()
+            assert std.shape == risks.shape
+            self._slip_std = std.to(dev)
+            _capi.check(lib.bn_mppi_set_slip_std(self._handle, 0, C.c_void_p(self._slip_std.data_ptr()), _capi.BN_MEM_DEVICE))
         self.set_goal(inp["goal"])
 
         K, T = num_samples, horizon

@@ -107,8 +107,11 @@ def assert_within(m, tol=TOL_REF, ctx=""):
 
 # ---- reference-shaped stand-ins (duck-typed like the reference's objects) ----------
 class FakeGridMap:
-    def __init__(self, grid_size, resolution, x_limits=None, y_limits=None):
+    def __init__(self, grid_size, resolution, x_limits=None, y_limits=None, latent=None):
         self.grid_size, self.resolution = grid_size, resolution
+        if latent is not None:                           # (mean, std) of grid_map.distributions["latent_models"]
+            import torch
+            self.distributions = {"latent_models": torch.distributions.Normal(torch.as_tensor(latent[0]), torch.as_tensor(latent[1]))}
         c = grid_size * resolution / 2
         self.x_limits = tuple(x_limits) if x_limits is not None else (c - grid_size / 2 * resolution, c + grid_size / 2 * resolution)
         self.y_limits = tuple(y_limits) if y_limits is not None else self.x_limits

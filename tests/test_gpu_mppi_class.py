@@ -80,3 +80,26 @@ def test_observation_mode_dynamics_are_rejected_like_the_reference():
     dyn = FakeDynamics(np.zeros((16, 16), np.float32), gm, mode="observation")
     with pytest.raises(TypeError):
         MPPI(5, 64, 3, 2, dyn, FakeObjectives(torch.tensor([4, 4]), 0.3), torch.tensor([0.5, 0.5]), 0.5)
+
+
+def test_sampled_slip_opt_in_plans_with_observation_mode_dynamics():
+    """BASELINE config 3 through the drop-in class: observation-mode dynamics + sampled_slip=True read the latent
+    Normal(mean, std) of the grid map; the solve equals NativeMPPI's sampled-slip solve with the same seed."""
+    from helpers import FakeDynamics, FakeGridMap, FakeObjectives
+    from benchnav_amd import MPPI, NativeMPPI, synth
+    G, K, T = 64, 256, 15
+    mu = (synth.smooth_risk_map(G, 5) * 0.6).numpy(); sg = synth.slip_std_map(G, 5).numpy()
+    gm = FakeGridMap(G, 0.5, latent=(mu, sg))
+    dyn = FakeDynamics(np.zeros((G, G), np.float32), gm, mode="observation")
+    obj = FakeObjectives(torch.tensor([24.0, 22.0]), 0.3)
+    solver = MPPI(T, K, 3, 2, dyn, obj, torch.tensor([0.5, 0.5]), 0.5, seed=3, noise="philox", sampled_slip=True)
+    state = torch.tensor([9.0, 8.0, 0.4])
+    U, X = solver(state)
+    torch.cuda.synchronize()
+    assert U.shape == (T, 2) and X.shape == (1, T + 1, 3) and abs(float(solver._weights.sum()) - 1) < 1e-4
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, sampled_slip=True, seed=3, stream=0) as pl:
+        pl.set_map(mu); pl.set_slip_std(sg); pl.set_goal([24.0, 22.0])
+        us, xs = pl.solve(state.numpy())
+    assert np.array_equal(U.cpu().numpy(), us[0]) and np.array_equal(X[0].cpu().numpy(), xs[0])
+    with pytest.raises(TypeError):                       # inference-mode dynamics cannot be sampled
+        MPPI(T, K, 3, 2, FakeDynamics(mu, gm), obj, torch.tensor([0.5, 0.5]), 0.5, sampled_slip=True)
