@@ -282,7 +282,13 @@ def main():
             rl, _, _ = pll.kernel_ms()
             bytes_l = pll.algorithmic_bytes(injected_noise=False) * BL
             pll.close()
-            large = {"instances_per_launch": BL, "value": BL * nl / ell, "unit": "solves/s", "ms_per_launch": ell / nl * 1e3,
+            traffic_l = None
+            if os.path.exists(tpath):
+                try:
+                    traffic_l = json.load(open(tpath)).get(f"rollout_wave_{a.noise}_B{BL}")
+                except Exception:
+                    traffic_l = None
+            large = {"instances_per_launch": BL, "traffic": traffic_l, "value": BL * nl / ell, "unit": "solves/s", "ms_per_launch": ell / nl * 1e3,
                      "kernel": "bn::rollout_wave_kernel (one wave per 64 rollouts)", "kernel_ms": rl,
                      "hbm_frac": bytes_l / (rl * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_l}
             out["batched"] = {"instances_per_launch": B, "value": B * nb / elb, "unit": "solves/s", "large_batch": large,
