@@ -157,20 +157,25 @@ template <int GEO, bool LDSWIN, bool FIRST>
 __device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
                                            const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn)
 {
+    // Position strand first: update, clamp, cell index, and the gather goes out; the heading strand (wrap, sin/cos,
+    // ~27 instructions) then runs under the gather's LDS latency.  The scheduling barrier keeps the compiler from
+    // interleaving the two again (it used to issue the gather two thirds into the step).
     const float tv = c.trav * u0;
-    tn = c.th + (c.trav * u1) * p.dt;                                  // :88
+    const float dth = (c.trav * u1) * p.dt;
     // x and y advance in lockstep: packed multiply / multiply / add (same roundings as the scalar form)
     const v2f pos = v2f{c.x, c.y} + (v2f{tv, tv} * v2f{c.cs, c.sn}) * v2f{p.dt, p.dt};   // :86-87
     xn = pos.x;
     yn = pos.y;
-    if (BN_ABLATE & 64) c.th = tn; else
-    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);               // :90
     c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
     c.y = clampf(yn, p.y0, p.y_hi);                                    // :94
-    if (BN_ABLATE & 16) { c.sn = c.th * 0.5f; c.cs = 1.0f - c.th; } else
-    sincos_spec(c.th, c.sn, c.cs);
     if (BN_ABLATE & 32) { c.trav = 0.5f + 0.001f * c.x; } else
     c.trav = LDSWIN ? trav_window<GEO>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
+    __builtin_amdgcn_sched_barrier(0);
+    tn = c.th + dth;                                                   // :88
+    if (BN_ABLATE & 64) c.th = tn; else
+    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);               // :90
+    if (BN_ABLATE & 16) { c.sn = c.th * 0.5f; c.cs = 1.0f - c.th; } else
+    sincos_spec(c.th, c.sn, c.cs);
 }
 
 // One PlanetaryEnv.step (planetary_env.py:189-219) for instance b: observation-mode transit with the
