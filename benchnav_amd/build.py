@@ -9,8 +9,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbenchnav_mppi.so")
-SOURCES = ["mppi_kernels.hip", "mppi_capi.cpp", "risk_kernels.hip"]
-HEADERS = ["mppi_kernels.h", "bn_device_math.h", os.path.join("..", "..", "include", "benchnav_mppi.h")]
+# one translation unit per kernel family: they compile in parallel (the role kernel alone is 72 template instances)
+SOURCES = ["rollout_role_philox.hip", "rollout_role_kt2.hip", "rollout_role_t2k.hip", "rollout_wave.hip", "rollout_sampled.hip",
+           "mppi_kernels.hip", "mppi_capi.cpp", "risk_kernels.hip"]
+HEADERS = ["mppi_kernels.h", "mppi_device.h", "rollout_role.inc", "bn_device_math.h", os.path.join("..", "..", "include", "benchnav_mppi.h")]
 
 # -ffp-contract=off: the arithmetic spec fixes where FMAs are (explicit __builtin_fmaf only).
 # Division and sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
@@ -38,10 +40,27 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), *HIPCC_FLAGS, *extra_flags, "-x", "hip", *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc(), *compile_flags, *extra_flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((src, obj, subprocess.Popen(cmd)))
+    objs = []
+    for src, obj, proc in jobs:
+        if proc.wait() != 0:
+            for _, _, other in jobs:
+                other.wait()
+            raise RuntimeError(f"hipcc failed on {src}")
+        objs.append(obj)
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB_PATH
 
 

@@ -1,0 +1,757 @@
+// mppi_device.h -- device code shared by the kernel translation units of the MPPI planner: geometry and lookups,
+// the transit step, the environment step, softmin merges, the tail of a solve, the ticket merge, control production.
+// Everything here has internal linkage (anonymous namespace); each .hip file instantiates what it launches.
+#pragma once
+#include "mppi_kernels.h"
+#include "bn_device_math.h"
+
+#include <math.h>
+#include <algorithm>
+
+namespace bn {
+
+namespace {
+
+
+constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chunk c, consumers on c-1, producers on c+2
+
+// Timing ablations for tools/ablate.py (never set in the shipped library): bit 0 skip stage cost,
+// 1 skip fp64 accumulation, 2 skip X stores, 3 skip control tile + control cost, 4 skip sincos,
+// 5 skip the gather, 6 skip the heading wrap.
+#ifndef BN_ABLATE
+#define BN_ABLATE 0
+#endif
+#define BN_KEEP(v) asm volatile("" ::"v"(v))
+#ifdef BN_TIMING
+#define BN_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                          \
+            p.stamps[slot] = __builtin_readcyclecounter();                                               \
+    } while (0)
+#define BN_STAMP_ANY(slot)                                                                               \
+    do {                                                                                                 \
+        if (p.stamps && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_readcyclecounter(); \
+    } while (0)
+// per-workgroup trace (tools/block_trace.py): wall clock (100 MHz, chip-wide) at entry and exit, cycles, HW_ID
+#define BN_TRACE_BEGIN()                                                                                 \
+    const unsigned long long bn_tr_t0 = wall_clock64(), bn_tr_c0 = __builtin_readcyclecounter()
+#define BN_TRACE_END()                                                                                   \
+    do {                                                                                                 \
+        if (p.stamps && threadIdx.x == 0) {                                                              \
+            unsigned long long *r = p.stamps + 64 + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);   \
+            r[0] = bn_tr_t0; r[1] = wall_clock64(); r[2] = __builtin_readcyclecounter() - bn_tr_c0;      \
+            r[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
+        }                                                                                                \
+    } while (0)
+#else
+#define BN_STAMP(slot) do { } while (0)
+#define BN_STAMP_ANY(slot) do { } while (0)
+#define BN_TRACE_BEGIN() do { } while (0)
+#define BN_TRACE_END() do { } while (0)
+#endif
+
+// Geometry specialisations of the cell index ((p - origin) / res).floor().int()  (grid_map.py:195-209):
+//   kGeoGeneral  true division            kGeoPow2  res is a power of two: * (1/res) is bit-identical
+//   kGeoPow2Origin0  additionally origin == 0, so the subtraction is the identity
+enum Geo : int { kGeoGeneral = 0, kGeoPow2 = 1, kGeoPow2Origin0 = 2 };
+
+struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; };   // window origin (cells), as floats, edge, edge-1
+
+template <int GEO>
+__device__ __forceinline__ int raw_cell(float v, float origin, float res, float inv_res)
+{
+    const float q = (GEO == kGeoPow2Origin0) ? v * inv_res : (GEO == kGeoPow2) ? (v - origin) * inv_res : (v - origin) / res;
+    return (int)floorf(q);                    // v_cvt_i32_f32 saturates
+}
+
+template <int GEO>
+__device__ __forceinline__ Win window_origin(const SolveParams &p, float sx, float sy)
+{
+    const int cx = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    const int cy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
+    Win w;
+    w.wx0 = min(max(cx - p.reach, 0), p.G - p.WN);
+    w.wy0 = min(max(cy - p.reach, 0), p.G - p.WN);
+    w.fx0 = (float)w.wx0; w.fy0 = (float)w.wy0; w.fwn = (float)p.WN; w.fwm1 = (float)(p.WN - 1);
+    return w;
+}
+
+// Stage the reachable window as traversability: trav = 1 - clamp(risk, 0, 1)
+// (reference traversability_model.py:72).  Rows of the window are contiguous
+// runs of the map rows, so the loads coalesce per row.
+__device__ __forceinline__ void stage_window(float *win, const float *__restrict__ map, const Win w,
+                                             int WN, int G, int tid, int nthreads)
+{
+    const int n = WN * WN;
+    for (int e = tid; e < n; e += nthreads) {
+        const int r = e / WN;
+        const int c = e - r * WN;
+        const float risk = map[(size_t)(w.wy0 + r) * G + (w.wx0 + c)];
+        win[e] = 1.0f - clampf(risk, 0.0f, 1.0f);
+    }
+}
+
+// Traversability at (x, y): index clamp (grid_map.py:209) then the gather.  With the LDS window the
+// two clamps (map, then window) collapse into one: the window lies inside the map, so clamping
+// i - wx0 to [0, WN-1] gives the same cell for every i (in, left of, or right of the map).
+// SAFE additionally bounds the raw index first, for a caller-supplied start state of any magnitude.
+template <int GEO, bool LDSWIN, bool SAFE>
+__device__ __forceinline__ float trav_lookup(const SolveParams &p, const float *win,
+                                             const float *__restrict__ map, const Win w, float x, float y)
+{
+    int ix = raw_cell<GEO>(x, p.x0, p.res, p.inv_res);
+    int iy = raw_cell<GEO>(y, p.y0, p.res, p.inv_res);
+    if (LDSWIN) {
+        if (SAFE) { ix = clampi(ix, 0, p.G - 1); iy = clampi(iy, 0, p.G - 1); }
+        const int li = clampi(ix - w.wx0, 0, p.WN - 1);
+        const int lj = clampi(iy - w.wy0, 0, p.WN - 1);
+        return win[(int)__umul24((unsigned)lj, (unsigned)p.WN) + li];
+    }
+    ix = clampi(ix, 0, p.G - 1);
+    iy = clampi(iy, 0, p.G - 1);
+    return 1.0f - clampf(map[(size_t)iy * p.G + ix], 0.0f, 1.0f);
+}
+
+// In-loop gather: (x, y) already lies inside the map limits.  The window-relative cell is computed in
+// the float domain: q = (x - origin)/res as the reference rounds it, then q - wx0 (exact: an integer
+// no larger than q is subtracted), floor, clamp to the window, row * WN + col (exact small integers),
+// one conversion.  Same cell as trav_lookup<..., false> for every in-limits position.
+template <int GEO>
+__device__ __forceinline__ float trav_window(const SolveParams &p, const float *win, const Win w, float x, float y)
+{
+    v2f q;
+    const v2f xy = {x, y}, ir = {p.inv_res, p.inv_res}, nw = {-w.fx0, -w.fy0};
+    if (GEO == kGeoPow2Origin0) {
+        q = __builtin_elementwise_fma(xy, ir, nw);                      // one v_pk_fma_f32
+    } else if (GEO == kGeoPow2) {
+        q = __builtin_elementwise_fma(xy - v2f{p.x0, p.y0}, ir, nw);
+    } else {
+        q = v2f{(x - p.x0) / p.res, (y - p.y0) / p.res} + nw;
+    }
+    const float li = clampf(floorf(q.x), 0.0f, w.fwm1);
+    const float lj = clampf(floorf(q.y), 0.0f, w.fwm1);
+    return win[(int)__builtin_fmaf(lj, w.fwn, li)];
+}
+
+// Per-rollout recurrence state: the clamped/wrapped state t, its traversability, sin/cos of its heading.
+struct Chain { float x, y, th, sn, cs, trav; };
+
+// One UnicycleModel.transit (robot_model.py:59-100) plus the gather for the next step.
+// (xn, yn, tn) is what the reference leaves in slot t (un-clamped, un-wrapped); the chain
+// advances to the clamped/wrapped state t+1.  The two dependent strands -- heading (wrap, sincos) and
+// position (clamp, cell index, LDS gather) -- are independent after `trav` and overlap in issue.
+// u0, u1 already lie in [u_min, u_max]: the re-clamp of robot_model.py:82-83 is the identity.
+template <int GEO, bool LDSWIN, bool FIRST>
+__device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
+                                           const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn)
+{
+    // Position strand first: update, clamp, cell index, and the gather goes out; the heading strand (wrap, sin/cos,
+    // ~27 instructions) then runs under the gather's LDS latency.  The scheduling barrier keeps the compiler from
+    // interleaving the two again (it used to issue the gather two thirds into the step).
+    const float tv = c.trav * u0;
+    const float dth = (c.trav * u1) * p.dt;
+    // x and y advance in lockstep: packed multiply / multiply / add (same roundings as the scalar form)
+    const v2f pos = v2f{c.x, c.y} + (v2f{tv, tv} * v2f{c.cs, c.sn}) * v2f{p.dt, p.dt};   // :86-87
+    xn = pos.x;
+    yn = pos.y;
+    c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
+    c.y = clampf(yn, p.y0, p.y_hi);                                    // :94
+    if (BN_ABLATE & 32) { c.trav = 0.5f + 0.001f * c.x; } else
+    c.trav = LDSWIN ? trav_window<GEO>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
+    __builtin_amdgcn_sched_barrier(0);
+    tn = c.th + dth;                                                   // :88
+    if (BN_ABLATE & 64) c.th = tn; else
+    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);               // :90
+    if (BN_ABLATE & 16) { c.sn = c.th * 0.5f; c.cs = 1.0f - c.th; } else
+    sincos_spec(c.th, c.sn, c.cs);
+}
+
+// One PlanetaryEnv.step (planetary_env.py:189-219) for instance b: observation-mode transit with the
+// latent slip sampled at the current cell (traversability_model.py:65-69: Normal(mean, std)[cell].sample()
+// = z * std + mean), then the goal test.  An instance already within goal_thr of its goal is frozen.
+// Every workgroup that needs the next state evaluates this itself: same inputs, same operations.
+struct EnvStep { float x, y, th, reward; bool reached, frozen; };
+
+template <int GEO>
+__device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, float sx, float sy, float sth, float u0, float u1,
+                                               const float *z_ptr, uint64_t step)
+{
+    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
+    EnvStep r;
+    const float d0x = sx - gx, d0y = sy - gy;
+    r.frozen = sqrt_cr(d0x * d0x + d0y * d0y) < p.goal_thr;          // terminated at an earlier step
+    const int ix = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    const int iy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
+    const size_t cell = (size_t)b * p.map_stride + (size_t)iy * p.G + ix;
+    float z;
+    if (z_ptr) {
+        z = z_ptr[b];
+    } else {
+        const u32x4 q = philox4x32_10(u32x4{(uint32_t)b, (uint32_t)step, (uint32_t)(step >> 32), 0x454e5631u},
+                                      (uint32_t)p.env_seed, (uint32_t)(p.env_seed >> 32));
+        float z1;
+        box_muller(q.x, q.y, z, z1);
+    }
+    const float slip = z * p.lat_std[cell] + p.lat_mean[cell];
+    const float trav = 1.0f - clampf(slip, 0.0f, 1.0f);
+    const float v = clampf(u0, p.umin0, p.umax0), om = clampf(u1, p.umin1, p.umax1);   // robot_model.py:82-83
+    float sn, cs;
+    sincos_spec(sth, sn, cs);
+    const float xn = sx + ((trav * v) * cs) * p.env_dt;
+    const float yn = sy + ((trav * v) * sn) * p.env_dt;
+    const float tn = sth + (trav * om) * p.env_dt;
+    r.x = r.frozen ? sx : clampf(xn, p.x0, p.x_hi);
+    r.y = r.frozen ? sy : clampf(yn, p.y0, p.y_hi);
+    r.th = r.frozen ? sth : wrap_angle(tn);
+    r.reward = trav;
+    const float dx = r.x - gx, dy = r.y - gy;
+    r.reached = sqrt_cr(dx * dx + dy * dy) < p.goal_thr;             // planetary_env.py:215-217
+    return r;
+}
+
+// Sampled-slip helpers (BASELINE config 3, see rollout_sampled_kernel): every lookup evaluates the observation-mode
+// traversability 1 - clamp(z*std + mean, 0, 1) (traversability_model.py:65-69) with its own standard normal z.
+__device__ __forceinline__ float trav_from_slip(float mu, float sd, float z)
+{
+    const float slip = z * sd + mu;                   // Normal.sample(): normal_(0,1).mul_(std).add_(mean)
+    return 1.0f - clampf(slip, 0.0f, 1.0f);
+}
+
+// Cell of a position of any magnitude, as map index (iy * G + ix) or, with the window, window index.
+template <int GEO, bool LDSWIN>
+__device__ __forceinline__ int slip_cell_safe(const SolveParams &p, const Win w, float x, float y)
+{
+    const int ix = clampi(raw_cell<GEO>(x, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    const int iy = clampi(raw_cell<GEO>(y, p.y0, p.res, p.inv_res), 0, p.G - 1);
+    if (LDSWIN) return clampi(iy - w.wy0, 0, p.WN - 1) * p.WN + clampi(ix - w.wx0, 0, p.WN - 1);
+    return iy * p.G + ix;
+}
+
+// Window cell of a position within (or a step beyond) the map limits, float domain as in trav_window.
+template <int GEO>
+__device__ __forceinline__ int slip_cell_window(const SolveParams &p, const Win w, float x, float y)
+{
+    v2f q;
+    const v2f xy = {x, y}, ir = {p.inv_res, p.inv_res}, nw = {-w.fx0, -w.fy0};
+    if (GEO == kGeoPow2Origin0) q = __builtin_elementwise_fma(xy, ir, nw);
+    else if (GEO == kGeoPow2) q = __builtin_elementwise_fma(xy - v2f{p.x0, p.y0}, ir, nw);
+    else q = v2f{(x - p.x0) / p.res, (y - p.y0) / p.res} + nw;
+    const float li = clampf(floorf(q.x), 0.0f, w.fwm1);
+    const float lj = clampf(floorf(q.y), 0.0f, w.fwm1);
+    return (int)__builtin_fmaf(lj, w.fwn, li);
+}
+
+// One observation-mode transit (robot_model.py:59-100) of the sampled-slip chain on the LDS window of (mean, std)
+// pairs: state (x, y, th) with heading (sn, cs) and window cell e advances; (xn, yn, tn) is what slot t keeps.
+struct SlipChain { float x, y, th, sn, cs; int e; };
+
+template <int GEO, bool FIRST>
+__device__ __forceinline__ void slip_chain_step(const SolveParams &p, const float2 *win2, const Win w, SlipChain &c, float u0,
+                                                float u1, float z, float &xn, float &yn, float &tn)
+{
+    const float2 ms = win2[c.e];
+    const float trav = trav_from_slip(ms.x, ms.y, z);                  // robot_model.py:75
+    const float tv = trav * u0;
+    tn = c.th + (trav * u1) * p.dt;
+    xn = c.x + (tv * c.cs) * p.dt;
+    yn = c.y + (tv * c.sn) * p.dt;
+    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);
+    c.x = clampf(xn, p.x0, p.x_hi);
+    c.y = clampf(yn, p.y0, p.y_hi);
+    sincos_spec(c.th, c.sn, c.cs);
+    c.e = slip_cell_window<GEO>(p, w, c.x, c.y);
+}
+
+// Wave-wide butterfly reductions (ds_bpermute).  A DPP row-scan formulation was measured 0.25 us faster
+// per launch but hipcc's DPP combiner mis-folds the update_dpp + add pairs inside this kernel (wrong sums
+// on hardware, correct in an isolated test kernel), so the shuffle form stays.
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------
+// Softmin merge and the tail of a solve (shared by the finish kernel, the aux block of the
+// pipelined rollout kernel, and the rollout blocks' own prologue merge).
+// ------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool is_max)
+{
+    v = is_max ? wave_max(v) : wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < NT / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    __syncthreads();
+    return r;
+}
+
+// Device-scope accesses that bypass the per-XCD L2 (sc1): what lets workgroups on different XCDs exchange their
+// partials inside one launch without a full L2 write-back / invalidate (see ticket_merge).
+__device__ __forceinline__ void store_agent(float *ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_agent(const float *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Merge the nblk per-block statistics (max z, sum e, sum e*u) of one instance into
+//   U*[j] = sum_k w_k u_k[j]      mppi.py:193-199
+// written to us[0..2T) (LDS).  Deterministic: every caller (256 threads) gets bit-identical values,
+// which is what lets each rollout block of the next solve recompute the warm-start mean on its own.
+// LDS scratch: sc[nblk], red[4].  Returns (max z, sum exp) for the weights.
+constexpr int kMergePrefetch = 16;
+struct MergeLoads { float v[kMergePrefetch]; float mi, si; int j; };
+
+// Issue every load of the few-blocks merge (nblk <= 64) without consuming any: lets the caller put
+// other memory traffic (the window staging) in flight underneath.
+template <bool AGENT = false>
+__device__ __forceinline__ MergeLoads merge_issue(const float *__restrict__ part, int nblk, int T, int tid)
+{
+#define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
+    const int PS = 2 + 2 * T;
+    const int lane = tid & 63;
+    MergeLoads L;
+    L.j = tid < 2 * T ? tid : 0;
+#pragma unroll
+    for (int i = 0; i < kMergePrefetch; ++i) L.v[i] = BN_PLD((size_t)min(i, nblk - 1) * PS + 2 + L.j);
+    const bool has = lane < nblk;
+    L.mi = has ? BN_PLD((size_t)lane * PS) : -INFINITY;
+    L.si = has ? BN_PLD((size_t)lane * PS + 1) : 0.0f;
+    return L;
+#undef BN_PLD
+}
+
+// Two-level merge for more than 64 partial rows (K > 4096): rows are first merged in groups of kGroupRows
+// consecutive rows, each relative to its group's max -- by whichever wave(s) get the job: a wave of the stand-alone
+// tail, or the waves of the last rollout workgroup of the group to finish (ticket) -- then the group rows are merged
+// like ordinary partials.  One definition for every caller, so the result does not depend on who ran it.
+constexpr int kGroupRows = 16;
+
+// Rows [row0, row0 + nrows) of `part` -> one row `gout` = (group max, sum e, sum e*u[2T]).  One wave; it handles the
+// 64-column blocks cb0, cb0 + cbstep, ... (several waves may share a group: they derive identical scales).
+template <bool AGENT, bool AGENT_STORE>
+__device__ __forceinline__ void merge_group(const float *__restrict__ part, int row0, int nrows, int T, int lane, int cb0,
+                                            int cbstep, float *gout)
+{
+#define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
+#define BN_PST(ptr, val) do { if (AGENT_STORE) store_agent((ptr), (val)); else *(ptr) = (val); } while (0)
+    const int PS = 2 + 2 * T;
+    const bool has = lane < nrows;
+    const float mi = has ? BN_PLD((size_t)(row0 + lane) * PS) : -INFINITY;
+    const float si = has ? BN_PLD((size_t)(row0 + lane) * PS + 1) : 0.0f;
+    float v[kGroupRows];
+    int jj = lane + 64 * cb0;
+#pragma unroll
+    for (int r = 0; r < kGroupRows; ++r) v[r] = (r < nrows && jj < 2 * T) ? BN_PLD((size_t)(row0 + r) * PS + 2 + jj) : 0.0f;
+    const float mg = wave_max(mi);
+    const float f = has ? expf(mi - mg) : 0.0f;
+    const float sg = wave_sum(si * f);
+    const int fb = __float_as_int(f);
+    for (int cb = cb0;;) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < kGroupRows; ++r) acc = __builtin_fmaf(v[r], __int_as_float(__builtin_amdgcn_readlane(fb, r)), acc);   // f == 0 past nrows
+        if (jj < 2 * T) BN_PST(gout + 2 + jj, acc);
+        cb += cbstep;
+        if (64 * cb >= 2 * T) break;
+        jj = lane + 64 * cb;
+#pragma unroll
+        for (int r = 0; r < kGroupRows; ++r) v[r] = (r < nrows && jj < 2 * T) ? BN_PLD((size_t)(row0 + r) * PS + 2 + jj) : 0.0f;
+    }
+    if (cb0 == 0 && lane == 0) { BN_PST(gout, mg); BN_PST(gout + 1, sg); }
+#undef BN_PLD
+#undef BN_PST
+}
+
+// BIG = false leaves the two-level code out of callers that never see more than 64 rows (the rollout kernels'
+// prologue / aux / ticket merges): it costs them registers.
+template <int NT, bool AGENT = false, bool BIG = false>
+__device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
+                                               float *red, int tid, float &m_out, float &S_out, const MergeLoads *pre)
+{
+#define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
+    const int PS = 2 + 2 * T;
+    const int lane = tid & 63;
+    float m, S;
+    if (nblk <= 64) {
+        // Few blocks (K <= 4096): every wave reduces the nblk (max, sum) pairs itself -- same inputs,
+        // same operations, so all waves (and all workgroups) hold identical m, S and scales -- and all
+        // loads are issued before the first use: one memory round trip, one barrier.
+        const MergeLoads L = pre ? *pre : merge_issue<AGENT>(part, nblk, T, tid);
+        m = wave_max(L.mi);
+        const float f = lane < nblk ? expf(L.mi - m) : 0.0f;       // scale of block `lane`; 0 past nblk
+        S = wave_sum(L.si * f);
+        // scale of block i = lane i's f, read with v_readlane (ignores EXEC): only the lanes with jj < 2T enter the
+        // loop below, and a ds_bpermute shuffle returns nothing from the lanes that did not
+        const int fb = __float_as_int(f);
+#define BN_SCALE(i) __int_as_float(__builtin_amdgcn_readlane(fb, (i)))
+        for (int jj = tid; jj < 2 * T; jj += NT) {
+            float acc = 0.0f;
+            if (jj == L.j) {
+#pragma unroll
+                for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], BN_SCALE(i), acc);   // f == 0 past nblk
+                for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), BN_SCALE(i), acc);
+            } else {
+                for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), BN_SCALE(i), acc);
+            }
+            us[jj] = acc / S;
+        }
+#undef BN_SCALE
+    } else if (BIG && nblk <= 64 * kGroupRows) {
+        // two-level (see merge_group): groups dealt to the waves, group rows in LDS, then the few-rows merge above
+        constexpr int NW = NT / 64;
+        const int ng = (nblk + kGroupRows - 1) / kGroupRows;
+        float *grows = red + 32;                         // ng x PS
+        for (int g = tid >> 6; g < ng; g += NW)
+            if constexpr (BIG) merge_group<AGENT, false>(part, g * kGroupRows, min(kGroupRows, nblk - g * kGroupRows), T, lane, 0, 1, grows + (size_t)g * PS);
+        __syncthreads();
+        merge_partials<NT, false, false>(grows, ng, T, us, sc, red, tid, m, S, nullptr);
+        m_out = m;
+        S_out = S;
+        return;
+    } else {
+        // more than 1024 workgroups (K > 65536): plain column sums in row order (independent of NT as well)
+        float mm = -INFINITY;
+        for (int i = tid; i < nblk; i += NT) mm = fmaxf(mm, BN_PLD((size_t)i * PS));
+        m = block_reduce<NT>(mm, red, tid, true);
+        float s = 0.0f;
+        for (int i = tid; i < nblk; i += NT) {
+            const float f = expf(BN_PLD((size_t)i * PS) - m);
+            sc[i] = f;
+            s += BN_PLD((size_t)i * PS + 1) * f;
+        }
+        S = block_reduce<NT>(s, red, tid, false);        // the barrier inside also publishes sc[]
+        for (int jj = tid; jj < 2 * T; jj += NT) {
+            float acc = 0.0f;
+            for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), sc[i], acc);
+            us[jj] = acc / S;
+        }
+    }
+    __syncthreads();
+    m_out = m;
+    S_out = S;
+#undef BN_PLD
+}
+
+// The tail of one solve of instance b: U* (and the next mean), softmin statistics, normalised weights,
+// a stable copy of the costs, and the batch-1 rollout X* of U*.  NT threads (320 as the aux workgroup, 1024 stand-alone for large K).
+// LDS: [ window | ustar 2T | scale nblk | red 32 | group rows ceil(nblk/16) x (2+2T) if nblk > 64 | sampled mode: draws, (mean, std) window ]
+template <int GEO, bool LDSWIN, int NT, bool BIG = false>
+__device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
+                                            const float *state_all, float *smem)
+{
+    // p.tail_merged: U* and the softmin statistics of this solve were merged already (ticket merge of the sampled
+    // kernel, which also wrote the next mean); they come from (ustar_prev, stats_prev).
+    const int T = p.T, K = p.K, nblk = p.nblk, PS = 2 + 2 * p.T;
+    float *win = smem;
+    float *us = win + (LDSWIN ? p.WN * p.WN : 0);
+    float *sc = us + 2 * T;
+    float *red = sc + nblk;
+
+    const int tid = threadIdx.x;
+    const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
+    const float *part = part_all + (size_t)b * nblk * PS;
+    const float sx = state_all[b * 3 + 0], sy = state_all[b * 3 + 1], sth = state_all[b * 3 + 2];
+    BN_STAMP(8);
+
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (LDSWIN && !p.slip_on) {
+        w = window_origin<GEO>(p, sx, sy);
+        stage_window(win, map, w, p.WN, p.G, tid, NT);
+    }
+    BN_STAMP(9);
+
+    float m, S;
+    if (p.tail_merged) {
+        for (int j = tid; j < 2 * T; j += NT) {
+            const float u = p.ustar_prev[(size_t)b * 2 * T + j];
+            us[j] = u;
+            p.ustar[(size_t)b * 2 * T + j] = u;
+        }
+        m = p.stats_prev[b * 2 + 0];
+        S = p.stats_prev[b * 2 + 1];
+        __syncthreads();
+    } else {
+        merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, nullptr);
+        for (int j = tid; j < 2 * T; j += NT) {
+            p.ustar[(size_t)b * 2 * T + j] = us[j];
+            p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
+        }
+    }
+    if (tid == 0) {
+        p.stats[b * 2 + 0] = m;
+        p.stats[b * 2 + 1] = S;
+    }
+    if (p.env_on && tid == 64) {
+        // the environment step that follows this solve: apply U*[0], log state, reward and goal arrival
+        const EnvStep e = env_advance<GEO>(p, b, sx, sy, sth, us[0], us[1], p.env_z, (uint64_t)p.ep_index);
+        const size_t B = p.B;
+        float *row = p.ep_states + ((size_t)(p.ep_index + 1) * B + b) * 3;
+        row[0] = e.x; row[1] = e.y; row[2] = e.th;
+        p.env_state[b * 3 + 0] = e.x; p.env_state[b * 3 + 1] = e.y; p.env_state[b * 3 + 2] = e.th;
+        p.ep_reward[(size_t)p.ep_index * B + b] = e.reward;
+        p.ep_action[((size_t)p.ep_index * B + b) * 2 + 0] = us[0];
+        p.ep_action[((size_t)p.ep_index * B + b) * 2 + 1] = us[1];
+        if (p.ep_index == 0) {
+            float *row0 = p.ep_states + (size_t)b * 3;
+            row0[0] = sx; row0[1] = sy; row0[2] = sth;
+        }
+        if (e.reached && !e.frozen && p.ep_done[b] < 0) p.ep_done[b] = p.ep_index;
+    }
+    BN_STAMP(10);
+
+    if (p.slip_on) {
+        // sampled-slip mode: the optimal rollout draws a fresh slip per transit as well (mppi.py:202-214 with
+        // traversability_model.py:65-69).  Draws and the (mean, std) window are staged by all threads first.
+        const float *__restrict__ sg = p.slip_std + (size_t)b * p.map_stride;
+        float *zol = red + 32 + ((nblk > 64 && nblk <= 64 * kGroupRows) ? ((nblk + kGroupRows - 1) / kGroupRows) * PS : 0);                      // T + 4 draws
+        float2 *win2 = reinterpret_cast<float2 *>((reinterpret_cast<uintptr_t>(zol + ((T + 7) & ~3)) + 7) & ~(uintptr_t)7);
+        if (p.zo) {
+            for (int t = tid; t < T; t += NT) zol[t] = p.zo[(size_t)b * T + t];
+        } else {
+            for (int j = tid; 4 * j < T; j += NT) philox_slip_block(p.seed, p.tail_solve, (uint32_t)b, 0xffffffffu, (uint32_t)j, zol + 4 * j);
+        }
+        if (LDSWIN) {
+            w = window_origin<GEO>(p, sx, sy);
+            for (int e = tid; e < p.WN * p.WN; e += NT) {
+                const int r = e / p.WN, c = e - r * p.WN;
+                const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
+                win2[e] = make_float2(map[g], sg[g]);
+            }
+        }
+        __syncthreads();
+        BN_STAMP(12);
+        if (tid == 0) {
+            float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
+            float xn, yn, tn;
+            if (LDSWIN) {
+                SlipChain c;
+                c.x = sx; c.y = sy; c.th = sth;
+                sincos_spec(c.th, c.sn, c.cs);
+                c.e = slip_cell_safe<GEO, true>(p, w, sx, sy);
+                slip_chain_step<GEO, true>(p, win2, w, c, us[0], us[1], zol[0], xn, yn, tn);
+                Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
+                int t = 1;
+                for (; t + 4 <= T; t += 4) {                 // controls and draws of four steps read up front
+                    float uq[4][3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; uq[i][2] = zol[t + i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        slip_chain_step<GEO, false>(p, win2, w, c, uq[i][0], uq[i][1], uq[i][2], xn, yn, tn);
+                        Xs[3 * (t + i)] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
+                    }
+                }
+                for (; t < T; ++t) {
+                    slip_chain_step<GEO, false>(p, win2, w, c, us[2 * t], us[2 * t + 1], zol[t], xn, yn, tn);
+                    Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+                }
+                Xs[3 * T] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
+                BN_STAMP(11);
+            } else {
+                float x = sx, y = sy, th = sth;
+                for (int t = 0; t < T; ++t) {
+                    const int e = slip_cell_safe<GEO, false>(p, w, x, y);
+                    const float trav = trav_from_slip(map[e], sg[e], zol[t]);
+                    float sn, cs;
+                    sincos_spec(th, sn, cs);
+                    xn = x + ((trav * us[2 * t]) * cs) * p.dt; yn = y + ((trav * us[2 * t]) * sn) * p.dt;
+                    tn = th + (trav * us[2 * t + 1]) * p.dt;
+                    Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+                    x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
+                }
+                Xs[3 * T] = x; Xs[3 * T + 1] = y; Xs[3 * T + 2] = th;
+            }
+        }
+    }
+    if (p.slip_on && tid < 64) {
+        // wave 0: thread 0 ran the sampled chain above
+    } else if (tid == 0) {
+        // optimal_state_seq: batch-1 rollout of U* with the same aliasing (mppi.py:202-214)
+        Chain c;
+        c.x = sx; c.y = sy; c.th = sth;
+        sincos_spec(c.th, c.sn, c.cs);
+        c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
+        float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
+        float xn, yn, tn;
+        chain_step<GEO, LDSWIN, true>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
+        Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
+        int t = 1;
+        for (; t + 4 <= T; t += 4) {                       // controls of four steps read up front (LDS latency off the chain)
+            float uq[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                chain_step<GEO, LDSWIN, false>(p, win, map, w, c, uq[i][0], uq[i][1], xn, yn, tn);
+                Xs[3 * (t + i) + 0] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
+            }
+        }
+        for (; t < T; ++t) {
+            chain_step<GEO, LDSWIN, false>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn);
+            Xs[3 * t + 0] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+        }
+        Xs[3 * T + 0] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
+        BN_STAMP(11);
+    } else if (NT > 64 && tid >= 64) {
+        // _weights = softmax(-costs / lambda)   mppi.py:193
+        const float *cost = cost_all + (size_t)b * K;
+        float *wout = p.w + (size_t)b * K;
+        float *cout = p.cost_out + (size_t)b * K;
+        for (int k = tid - 64; k < K; k += NT - 64) {
+            const float ck = cost[k];
+            cout[k] = ck;
+            wout[k] = expf((-ck) / p.lambda_ - m) / S;
+        }
+    }
+    if constexpr (NT == 64) {                          // single-wave tail: the weights follow the X* rollout
+        const float *cost = cost_all + (size_t)b * K;
+        float *wout = p.w + (size_t)b * K;
+        float *cout = p.cost_out + (size_t)b * K;
+        for (int k = tid; k < K; k += 64) {
+            const float ck = cost[k];
+            cout[k] = ck;
+            wout[k] = expf((-ck) / p.lambda_ - m) / S;
+        }
+    }
+}
+
+// Ticket merge: every workgroup of instance b publishes its partials, takes a ticket, and the one that draws the
+// last ticket merges all of them (fixed order: the result does not depend on which workgroup that is) into
+// U* = the next mean, plus the softmin statistics the tail needs for the weights.  Saves the merge launch.
+// With more than 64 workgroups the merge is the two-level one (merge_group): the last workgroup of each group of 16
+// merges its group (its waves split the columns: one memory round trip), the last group to finish merges the groups.
+// The partials travel as device-scope sc1 stores / loads (store_agent / load_agent): once every wave has seen its
+// stores acknowledged (vmcnt 0) and the workgroup has met at the barrier, the ticket is taken.  No __threadfence:
+// that writes back / invalidates the whole L2 once per workgroup (measured: +18 us per launch at 128 workgroups).
+// Ticket counters: kTicketStride ints per instance, [0] = groups (or workgroups) done, [1 + g] = workgroups of group g.
+// LDS scratch: [ us 2T | sc nblk | red 32 | flag ].  Needs nblk <= 1024 (two levels).
+constexpr int kTicketStride = 1 + 64;
+
+template <int NT>
+__device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, float *scratch)
+{
+    const int T = p.T, tid = threadIdx.x, PS = 2 + 2 * p.T;
+    float *us = scratch, *sc = us + 2 * T, *red = sc + p.nblk;
+    int *flag = reinterpret_cast<int *>(red + 32);       // at most 64 rows reach merge_partials here: no group rows in LDS
+    int *ticket = p.ticket + (size_t)b * kTicketStride;
+    const float *part = p.part + (size_t)b * p.nblk * PS;
+    const float *rows = part;
+    int nrows = p.nblk;
+    if (p.nblk > 64) {
+        const int g = blockIdx.x / kGroupRows, ng = (p.nblk + kGroupRows - 1) / kGroupRows;
+        const int in_group = min(kGroupRows, p.nblk - g * kGroupRows);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *flag = (atomicAdd(ticket + 1 + g, 1) == in_group - 1) ? 1 : 0;
+        __syncthreads();
+        if (!*flag) return;
+        if (tid == 0) ticket[1 + g] = 0;
+        float *grow = p.gpart + ((size_t)b * 64 + g) * PS;
+        merge_group<true, true>(part, g * kGroupRows, in_group, T, tid & 63, tid >> 6, NT / 64, grow);
+        rows = p.gpart + (size_t)b * 64 * PS;
+        nrows = ng;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *flag = (atomicAdd(ticket, 1) == nrows - 1) ? 1 : 0;
+    __syncthreads();
+    if (!*flag) return;
+    BN_STAMP_ANY(6);
+    if (tid == 0) ticket[0] = 0;                       // ready for the next launch (ordered by the stream)
+    float m, S;
+    merge_partials<NT, true, false>(rows, nrows, T, us, sc, red, tid, m, S, nullptr);
+    for (int j = tid; j < 2 * T; j += NT) {
+        p.ustar_cur[(size_t)b * 2 * T + j] = us[j];
+        p.mean[(size_t)b * 2 * T + j] = us[j];         // _previous_action_seq = U*, no shift (mppi.py:217)
+    }
+    if (tid == 0) { p.stats_cur[b * 2 + 0] = m; p.stats_cur[b * 2 + 1] = S; }
+    BN_STAMP_ANY(7);
+}
+
+// Workgroup barrier that only drains LDS traffic: global stores of the consumer wave stay in flight.
+#define BN_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Producer: the clamped perturbed controls of steps t and t+1 (t even) of this lane's rollout,
+//   u = clamp(mean + sigma * eps, u_min, u_max)          mppi.py:152-157
+// written to the LDS control tile (and to HBM when _perturbed_action_seqs is materialised).
+template <int EPS, bool STORE_U>
+__device__ __forceinline__ void produce_pair(const SolveParams &p, const float *__restrict__ eps, int b, int kk, int t,
+                                             uint64_t solve, const float *ml, float *Ul, float *Ub, size_t Kp, int lane)
+{
+    float e[4];
+    const int t1 = min(t + 1, p.T - 1);
+    if (EPS == kEpsPhilox) {
+        philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), e);
+    } else if (EPS == kEpsKT2) {
+        const float *row = eps + ((size_t)b * p.K + kk) * p.T * 2;
+        const float2 v0 = *reinterpret_cast<const float2 *>(row + 2 * t);
+        const float2 v1 = *reinterpret_cast<const float2 *>(row + 2 * t1);
+        e[0] = v0.x; e[1] = v0.y; e[2] = v1.x; e[3] = v1.y;
+    } else {
+        const float *r0 = eps + ((size_t)b * p.T + t) * 2 * p.K;
+        const float *r1 = eps + ((size_t)b * p.T + t1) * 2 * p.K;
+        e[0] = r0[kk]; e[1] = r0[p.K + kk]; e[2] = r1[kk]; e[3] = r1[p.K + kk];
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int tt = t + s;
+        if (tt < p.T) {
+            const float u0 = clampf(ml[2 * tt] + p.sigma0 * e[2 * s], p.umin0, p.umax0);
+            const float u1 = clampf(ml[2 * tt + 1] + p.sigma1 * e[2 * s + 1], p.umin1, p.umax1);
+            Ul[(2 * tt) * kUPad + lane] = u0;
+            Ul[(2 * tt + 1) * kUPad + lane] = u1;
+            if (STORE_U) { float *Ut = Ub + (size_t)(2 * tt) * Kp; Ut[0] = u0; Ut[Kp] = u1; }
+        }
+    }
+}
+
+
+// The noise of steps t and t+1 (t even) of rollout kk: the library's Philox stream or the caller's arrays.
+template <int EPS>
+__device__ __forceinline__ void noise_pair(const SolveParams &p, int b, int kk, int t, float e[4])
+{
+    const int t1 = min(t + 1, p.T - 1);
+    if (EPS == kEpsPhilox) {
+        philox_eps_pair(p.seed, p.solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), e);
+    } else if (EPS == kEpsKT2) {
+        const float *row = p.eps + ((size_t)b * p.K + kk) * p.T * 2;
+        const float2 v0 = *reinterpret_cast<const float2 *>(row + 2 * t);
+        const float2 v1 = *reinterpret_cast<const float2 *>(row + 2 * t1);
+        e[0] = v0.x; e[1] = v0.y; e[2] = v1.x; e[3] = v1.y;
+    } else {
+        const float *r0 = p.eps + ((size_t)b * p.T + t) * 2 * p.K;
+        const float *r1 = p.eps + ((size_t)b * p.T + t1) * 2 * p.K;
+        e[0] = r0[kk]; e[1] = r0[p.K + kk]; e[2] = r1[kk]; e[3] = r1[p.K + kk];
+    }
+}
+
+template <typename Kern>
+hipError_t ensure_lds(Kern kern, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int geo_of(const SolveParams &p)
+{
+    if (!p.pow2) return kGeoGeneral;
+    return (p.x0 == 0.0f && p.y0 == 0.0f) ? kGeoPow2Origin0 : kGeoPow2;
+}
+
+static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256); }
+
+}  // namespace
+
+// launchers that live in their own translation units (one per kernel family)
+hipError_t launch_rollout_role_philox(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_role_kt2(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_role_t2k(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_wave(const SolveParams &p, EpsMode mode, hipStream_t s);
+
+}  // namespace bn

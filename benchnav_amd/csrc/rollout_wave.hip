@@ -1,0 +1,176 @@
+// rollout_wave.hip -- the one-wave-per-64-rollouts throughput variant of the rollout kernel.
+#include "mppi_device.h"
+
+namespace bn {
+
+namespace {
+
+// ------------------------------------------------------------------------------
+// Throughput variant of the rollout kernel: ONE wavefront per 64 rollouts does everything in step order -- per pair
+// of steps the noise and controls (in registers), then per step transit + gather, trajectory stores, stage and
+// control cost.  No ring, no barriers, no role split, no control tile in LDS: the controls go to HBM (the (T,2,Kp)
+// buffer of BN_FLAG_STORE_CONTROLS) and come back, L2-hot, for the weighted control sums -- lane = column there, one
+// 256-byte row of the 64 rollouts per column.  3.5 KB of LDS and one wave per workgroup, so a SIMD holds as many
+// workgroups as its registers allow (6) and they fill each other's issue gaps and memory waits.  A lone workgroup is
+// 2x slower than the role kernel's (the recurrence waits for everything else); with every SIMD full the kernel is
+// VALU-bound at ~7000 VALU instructions per workgroup against the role kernel's ~8700 + its skeleton (rocprofv3 SQ
+// counters, tools/pmc_sq.sh), and wins by 10-15 % from about 1500 workgroups per launch (96 instances of K=1024) on.
+// Same device functions in the same order per rollout: results are bit-identical to the role kernel.
+// grid = (ceil(K/64) [+1 aux], B), block = 64.  LDS: [ window | mean 2T | mean*inv_var 2T | e 64 | merge scratch ].
+// ------------------------------------------------------------------------------
+template <int EPS, int GEO, bool LDSWIN>
+__global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.x == p.nblk) {
+        finish_body<GEO, LDSWIN, 64>(p, blockIdx.y, p.part_prev, p.cost_prev, p.state_prev, smem);
+        return;
+    }
+    const int T = p.T, K = p.K;
+    float *win = smem;
+    float *ml = win + (LDSWIN ? p.WN * p.WN : 0);
+    float *mv = ml + 2 * T;
+    float *el = mv + 2 * T;
+    float *sc = el + 64;                              // merge scratch: nblk scales + 32
+    const int lane = threadIdx.x, b = blockIdx.y;
+    const int k = blockIdx.x * kRolloutsPerBlock + lane;
+    const bool active = k < K;
+    const int kk = active ? k : K - 1;
+    const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
+    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
+
+    const float *part_prev = p.part_prev + (size_t)b * p.nblk * (2 + 2 * T);
+    MergeLoads pre;
+    const bool pre_ok = p.mean_from_part && p.nblk <= 64;
+    if (pre_ok) pre = merge_issue(part_prev, p.nblk, T, lane);
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (LDSWIN) {
+        w = window_origin<GEO>(p, sx, sy);
+        stage_window(win, map, w, p.WN, p.G, lane, 64);
+    }
+    if (p.mean_from_part) {
+        float m_unused, S_unused;
+        merge_partials<64>(part_prev, p.nblk, T, ml, sc, sc + p.nblk, lane, m_unused, S_unused, pre_ok ? &pre : nullptr);
+        for (int j = lane; j < 2 * T; j += 64) mv[j] = ml[j] * ((j & 1) ? p.iv1 : p.iv0);
+    } else {
+        for (int j = lane; j < 2 * T; j += 64) {
+            const float m = p.mean[(size_t)b * 2 * T + j];
+            ml[j] = m;
+            mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);      // mean[t] @ inv_cov (diagonal), mppi.py:179-180
+        }
+    }
+    if (blockIdx.x == 0 && lane == 0) {
+        p.state_copy[b * 3 + 0] = sx; p.state_copy[b * 3 + 1] = sy; p.state_copy[b * 3 + 2] = sth;
+    }
+    __syncthreads();
+    const size_t Kp = (size_t)p.Kp;
+    float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
+    float *Ub = p.U + (size_t)b * T * 2 * Kp + k;
+
+    Chain c;
+    c.x = sx; c.y = sy; c.th = sth;                   // mppi.py:160
+    sincos_spec(c.th, c.sn, c.cs);
+    c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
+    double Sd = 0.0, Ad = 0.0;
+    // one step: transit (slot t keeps the un-clamped state), its stores, stage cost on the slot with the traversability
+    // of the clamped successor (same cell, grid_map.py:209), control cost; fp64 accumulation in step order
+#define BN_WAVE_STEP(FIRST, t, u0, u1)                                                                            \
+    do {                                                                                                          \
+        float xn, yn, tn;                                                                                         \
+        chain_step<GEO, LDSWIN, FIRST>(p, win, map, w, c, (u0), (u1), xn, yn, tn);                                \
+        float *Xt = Xb + (size_t)(3 * (t)) * Kp;                                                                  \
+        Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                                 \
+        const float dx = xn - gx, dy = yn - gy;                                                                   \
+        Sd += (double)(sqrt_cr(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));   /* objectives.py:47-53 */  \
+        Ad += (double)(p.lambda_ * (mv[2 * (t)] * (u0) + mv[2 * (t) + 1] * (u1)));      /* mppi.py:178-182 */      \
+    } while (0)
+    for (int t = 0; t < T; t += 2) {
+        float e[4];
+        noise_pair<EPS>(p, b, kk, t, e);
+        const float u0 = clampf(ml[2 * t] + p.sigma0 * e[0], p.umin0, p.umax0);          // mppi.py:152-157
+        const float u1 = clampf(ml[2 * t + 1] + p.sigma1 * e[1], p.umin1, p.umax1);
+        float *Ut = Ub + (size_t)(2 * t) * Kp;
+        Ut[0] = u0; Ut[Kp] = u1;
+        if (t == 0) BN_WAVE_STEP(true, t, u0, u1); else BN_WAVE_STEP(false, t, u0, u1);
+        if (t + 1 < T) {
+            const float v0 = clampf(ml[2 * t + 2] + p.sigma0 * e[2], p.umin0, p.umax0);
+            const float v1 = clampf(ml[2 * t + 3] + p.sigma1 * e[3], p.umin1, p.umax1);
+            Ut[2 * Kp] = v0; Ut[3 * Kp] = v1;
+            BN_WAVE_STEP(false, t + 1, v0, v1);
+        }
+    }
+#undef BN_WAVE_STEP
+    {
+        float *Xt = Xb + (size_t)(3 * T) * Kp;         // slot T: clamped / wrapped state
+        Xt[0] = c.x; Xt[Kp] = c.y; Xt[2 * Kp] = c.th;
+    }
+    const float dxT = c.x - gx, dyT = c.y - gy;
+    const float term = sqrt_cr(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);      // mppi.py:184
+    const float cost = ((float)Sd + term) + (float)Ad;                                          // mppi.py:186-190
+    if (active) p.cost[(size_t)b * K + k] = cost;
+    const float z = active ? (-cost) / p.lambda_ : -INFINITY;
+    const float zmax = wave_max(z);
+    const float e = active ? expf(z - zmax) : 0.0f;
+    const float esum = wave_sum(e);
+    el[lane] = e;
+    __syncthreads();                                   // e in LDS; this wave's control stores visible to all its lanes
+    float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+    if (lane == 0) { part[0] = zmax; part[1] = esum; }
+    // weighted control sums: lane = column j, whose 64 rollout values are one contiguous row of the (T,2,Kp) buffer
+    const float *Urow0 = p.U + (size_t)b * T * 2 * Kp + (size_t)blockIdx.x * kRolloutsPerBlock;
+    for (int j = lane; j < 2 * T; j += 64) {
+        const float4 *row = reinterpret_cast<const float4 *>(Urow0 + (size_t)j * Kp);
+        float acc = 0.0f;
+#pragma unroll
+        for (int q4 = 0; q4 < kRolloutsPerBlock / 4; ++q4) {
+            const float4 v = row[q4];
+            acc = __builtin_fmaf(el[4 * q4 + 0], v.x, acc);
+            acc = __builtin_fmaf(el[4 * q4 + 1], v.y, acc);
+            acc = __builtin_fmaf(el[4 * q4 + 2], v.z, acc);
+            acc = __builtin_fmaf(el[4 * q4 + 3], v.w, acc);
+        }
+        part[2 + j] = acc;
+    }
+}
+
+
+template <int EPS, int GEO>
+hipError_t launch_wave_g(const SolveParams &p, hipStream_t s)
+{
+    const dim3 grid(p.nblk + (p.have_prev ? 1 : 0), p.B);
+    const size_t lds = wave_lds_bytes(p);
+    if (p.WN > 0) {
+        hipError_t e = ensure_lds(rollout_wave_kernel<EPS, GEO, true>, lds);
+        if (e != hipSuccess) return e;
+        rollout_wave_kernel<EPS, GEO, true><<<grid, dim3(64), lds, s>>>(p);
+    } else {
+        hipError_t e = ensure_lds(rollout_wave_kernel<EPS, GEO, false>, lds);
+        if (e != hipSuccess) return e;
+        rollout_wave_kernel<EPS, GEO, false><<<grid, dim3(64), lds, s>>>(p);
+    }
+    return hipGetLastError();
+}
+
+template <int EPS>
+hipError_t launch_wave_e(const SolveParams &p, hipStream_t s)
+{
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: return launch_wave_g<EPS, kGeoPow2Origin0>(p, s);
+    case kGeoPow2: return launch_wave_g<EPS, kGeoPow2>(p, s);
+    default: return launch_wave_g<EPS, kGeoGeneral>(p, s);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_rollout_wave(const SolveParams &p, EpsMode mode, hipStream_t s)
+{
+    switch (mode) {
+    case kEpsPhilox: return launch_wave_e<kEpsPhilox>(p, s);
+    case kEpsKT2: return launch_wave_e<kEpsKT2>(p, s);
+    default: return launch_wave_e<kEpsT2K>(p, s);
+    }
+}
+
+}  // namespace bn
