@@ -106,7 +106,7 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "benchnav_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h")):
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "mppi_oracle" not in text and "liboracle" not in text, f
