@@ -527,6 +527,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             h->ep_len += 1;
         }
         p.wave_kernel = (h->wave_kernel && !h->in_episode) ? 1 : 0;
+        if (!p.wave_kernel && !p.store_u) p.U = nullptr;          // the buffer exists for the throughput kernel only
         BN_HIP(bn::launch_rollout(p, mode, h->stream));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;

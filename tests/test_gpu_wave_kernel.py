@@ -60,3 +60,24 @@ def test_wave_kernel_matches_oracle_and_is_the_default_for_large_batches():
             p = O.make_params(K, T, G, 0.5, insts[b].goal.numpy(), trig=O.TRIG_SPEC)
             orc = O.solve(p, insts[b].risk.numpy(), states[b], mean, eps[b])
             assert_oracle_parity(oracle_metrics(native_outputs(pl, us, xs, b), orc), ctx=f"instance {b}")
+
+
+def test_episodes_on_a_wave_eligible_handle_use_the_role_kernel_and_agree():
+    """A handle large enough for the throughput kernel still runs device-side episodes (closed loop) with the role
+    kernel; logs must equal those of a handle forced to the role kernel, and plain solves afterwards still work."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    K, T, G, B, n = 256, 12, 64, 320, 4                  # 320 x 5 workgroups > 1536
+    inst = synth.make_instance(G, seed=3)
+    lat_std = synth.slip_std_map(G, seed=3).numpy()
+    states0 = np.tile(inst.start.numpy(), (B, 1)) + 0.05 * np.arange(B)[:, None].astype(np.float32) % 3
+    logs = {}
+    for kern in ("auto", "role"):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, shared_map=True, seed=2, kernel=kern) as pl:
+            pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+            pl.env_attach(inst.risk.numpy() * 0.5, lat_std, seed=7)
+            st, rw, done = pl.episode(n, states0)
+            us, xs = pl.solve(st[-1])
+            logs[kern] = (st, rw, done, us, xs, pl.weights(5))
+    for a_, b_ in zip(logs["auto"], logs["role"]):
+        assert np.array_equal(a_, b_)
