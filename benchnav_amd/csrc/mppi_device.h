@@ -301,7 +301,7 @@ __device__ __forceinline__ float load_agent(const float *ptr) { return __hip_ato
 
 // Merge the nblk per-block statistics (max z, sum e, sum e*u) of one instance into
 //   U*[j] = sum_k w_k u_k[j]      mppi.py:193-199
-// written to us[0..2T) (LDS).  Deterministic: every caller (256 threads) gets bit-identical values,
+// written to us[0..2T) (LDS).  Deterministic: every caller (any thread count NT) gets bit-identical values,
 // which is what lets each rollout block of the next solve recompute the warm-start mean on its own.
 // LDS scratch: sc[nblk], red[4].  Returns (max z, sum exp) for the weights.
 constexpr int kMergePrefetch = 16;

@@ -26,7 +26,7 @@ namespace bn {
 namespace {
 
 // ------------------------------------------------------------------------------
-// Finish kernel.  grid = B, block = 256: finish_body for the latest solve (also the flush of the
+// Finish kernel.  grid = B, block = NT (320, or 1024 above 32 workgroups): finish_body for the latest solve (also the flush of the
 // pipelined mode).
 // ------------------------------------------------------------------------------
 template <int GEO, bool LDSWIN, int NT>
