@@ -110,3 +110,28 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "mppi_oracle" not in text and "liboracle" not in text, f
+
+
+def test_header_is_plain_c_and_the_integration_example_compiles():
+    """include/benchnav_mppi.h must be usable from C (the boundary is a C ABI): the caller shown in INTEGRATION.md
+    compiles as strict C99 against it."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```c\n(.*?)```", text, flags=re.S)
+    assert m, "INTEGRATION.md lost its C example"
+    body = m.group(1).replace("#include \"benchnav_mppi.h\"", "")
+    src = ("#include <stdio.h>\n#include \"benchnav_mppi.h\"\nstatic void apply(float a, float b) { (void)a; (void)b; }\n"
+           "int run(const float *risks, const float *state) {\n" + body + "\nreturn 0; }\n")
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        f.write(src)
+    try:
+        r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    finally:
+        os.unlink(f.name)
