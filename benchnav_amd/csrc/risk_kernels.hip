@@ -5,8 +5,10 @@
 //   expected_value   R = mean
 //   var              R = quantile_q( mean + std * z_i ),  linear interpolation (torch.quantile default)
 //   cvar             R = mean of the samples strictly above that quantile (nanmean of the masked tensor)
-// Here one wavefront owns one map cell: its num_samples draws live in LDS, are sorted with a bitonic
-// network, and only mean/std in and R out touch HBM (8 B + 4 B per cell instead of 4*num_samples B).
+// Here one wavefront owns one map cell and keeps its num_samples draws in REGISTERS (16 per lane at 1000 samples), as
+// order-preserving integer keys.  The two order statistics torch.quantile interpolates between are found by a
+// radix select over the key bits (32 rounds of compare + ballot + popcount: no sort, no LDS, no barrier), the tail
+// mean by one more pass.  Only mean/std in and R out touch HBM (8 B + 4 B per cell instead of 4*num_samples B).
 #include "../../include/benchnav_mppi.h"
 #include "bn_device_math.h"
 
@@ -18,7 +20,7 @@
 namespace bn {
 namespace {
 
-constexpr int kRiskWaves = 4;            // cells per workgroup (one wave each)
+constexpr int kRiskWaves = 4;            // cells per workgroup (one wave each, independent)
 
 __device__ __forceinline__ float wave_sum_f(float v)
 {
@@ -27,74 +29,94 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
-// P = power-of-two capacity >= num_samples (padding sorts to the end as +inf)
-template <int P>
+// float <-> unsigned key with the same order (negative floats reversed, sign bit flipped)
+__device__ __forceinline__ uint32_t key_of(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float value_of(uint32_t k)
+{
+    return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xffffffffu));
+}
+
+// R = draws per lane: capacity 64*R >= num_samples (padding = +inf sorts to the end)
+template <int R>
 __global__ __launch_bounds__(kRiskWaves * 64) void risk_map_kernel(const float *__restrict__ mean, const float *__restrict__ stdv,
                                                                    const float *__restrict__ z, float *__restrict__ out,
                                                                    int cells, int n, int metric, float qf, uint64_t seed)
 {
-    __shared__ float smem[kRiskWaves * P];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *buf = smem + wid * P;
+    const int cell = blockIdx.x * kRiskWaves + wid;
+    if (cell >= cells) return;                          // whole wave: no barrier anywhere below
     // rank arithmetic of torch.quantile: fp32 q * (n - 1), floor / ceil, weight = fractional part
     const float pos = qf * (float)(n - 1);
     const float lo_f = floorf(pos);
     const int lo = (int)lo_f, hi = (int)ceilf(pos);
     const float wgt = pos - lo_f;
+    const float mu = mean[cell], sg = stdv[cell];
 
-    for (int base = blockIdx.x * kRiskWaves; base < cells; base += gridDim.x * kRiskWaves) {
-        const int cell = base + wid;
-        const bool live = cell < cells;
-        const float mu = live ? mean[cell] : 0.0f, sg = live ? stdv[cell] : 0.0f;
-        if (z) {
-            for (int i = lane; i < P; i += 64)
-                buf[i] = (live && i < n) ? (z[(size_t)i * cells + cell] * sg + mu) : INFINITY;   // Normal.sample: normal_().mul_(std).add_(mean)
-        } else {
-            for (int i4 = lane; i4 < P / 4; i4 += 64) {
-                const u32x4 r = philox4x32_10(u32x4{(uint32_t)cell, (uint32_t)i4, 0x5249534bu, 0u}, (uint32_t)seed, (uint32_t)(seed >> 32));
-                float e[4];
-                box_muller(r.x, r.y, e[0], e[1]);
-                box_muller(r.z, r.w, e[2], e[3]);
+    uint32_t key[R];                                    // element index of key[r]: idx(r), below
+    if (z) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int i = 4 * i4 + s;
-                    buf[i] = (live && i < n) ? (e[s] * sg + mu) : INFINITY;
-                }
-            }
+        for (int r = 0; r < R; ++r) {
+            const int i = lane + 64 * r;
+            key[r] = key_of(i < n ? (z[(size_t)i * cells + cell] * sg + mu) : INFINITY);       // Normal.sample: normal_().mul_(std).add_(mean)
         }
-        __syncthreads();
-        // bitonic sort, ascending
-        for (int k = 2; k <= P; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = lane; t < P / 2; t += 64) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // lower index of the pair
-                    const int l = i | j;
-                    const float a = buf[i], b = buf[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { buf[i] = b; buf[l] = a; }
-                }
-                __syncthreads();
-            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < R / 4; ++j) {
+            const int i4 = lane + 64 * j;
+            const u32x4 q = philox4x32_10(u32x4{(uint32_t)cell, (uint32_t)i4, 0x5249534bu, 0u}, (uint32_t)seed, (uint32_t)(seed >> 32));
+            float e[4];
+            box_muller(q.x, q.y, e[0], e[1]);
+            box_muller(q.z, q.w, e[2], e[3]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) key[4 * j + s] = key_of((4 * i4 + s) < n ? (e[s] * sg + mu) : INFINITY);
         }
-        if (live) {
-            const float below = buf[lo], above = buf[hi];
-            // at::lerp: |w| < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
-            const float var = (fabsf(wgt) < 0.5f) ? below + wgt * (above - below) : above - (above - below) * (1.0f - wgt);
-            if (metric == 1) {
-                if (lane == 0) out[cell] = var;
-            } else {
-                float s = 0.0f, c = 0.0f;
-                for (int i = lane; i < n; i += 64) {
-                    const float x = buf[i];
-                    if (x > var) { s += x; c += 1.0f; }
-                }
-                s = wave_sum_f(s);
-                c = wave_sum_f(c);
-                if (lane == 0) out[cell] = s / c;            // nanmean: 0/0 = NaN when no sample exceeds the quantile
-            }
-        }
-        __syncthreads();
     }
+    // radix select of the key of rank lo (0-based, ascending): the largest prefix with #(key < prefix) <= lo
+    uint32_t klo = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = klo | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) cnt += __popcll(__ballot(key[r] < cand));
+        if (cnt <= lo) klo = cand;
+    }
+    // rank hi (= lo or lo + 1): the same key if it repeats past rank lo, else the smallest key above it
+    uint32_t khi = klo;
+    if (hi != lo) {
+        int cnt_le = 0;
+        uint32_t mn = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            cnt_le += __popcll(__ballot(key[r] <= klo));
+            mn = min(mn, key[r] > klo ? key[r] : 0xffffffffu);
+        }
+        if (cnt_le <= hi) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+            khi = mn;
+        }
+    }
+    const float below = value_of(klo), above = value_of(khi);
+    // at::lerp: |w| < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
+    const float var = (fabsf(wgt) < 0.5f) ? below + wgt * (above - below) : above - (above - below) * (1.0f - wgt);
+    if (metric == 1) {
+        if (lane == 0) out[cell] = var;
+        return;
+    }
+    float s = 0.0f, c = 0.0f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = z ? lane + 64 * r : 4 * (lane + 64 * (r >> 2)) + (r & 3);
+        const float x = value_of(key[r]);
+        if (i < n && x > var) { s += x; c += 1.0f; }
+    }
+    s = wave_sum_f(s);
+    c = wave_sum_f(c);
+    if (lane == 0) out[cell] = s / c;                   // nanmean: 0/0 = NaN when no sample exceeds the quantile
 }
 
 thread_local std::string g_risk_error;
@@ -146,14 +168,14 @@ int bn_risk_map_infer(int32_t device_id, void *stream, const float *mean, const 
                 RISK_HIP(hipMemcpyAsync(d_z, z, cells * (size_t)num_samples * 4, hipMemcpyHostToDevice, s));
             } else d_z = const_cast<float *>(z);
         }
-        const int blocks = (int)std::min<size_t>((cells + bn::kRiskWaves - 1) / bn::kRiskWaves, 256 * 8);
+        const int blocks = (int)((cells + bn::kRiskWaves - 1) / bn::kRiskWaves);
         const int m = metric == BN_RISK_VAR ? 1 : 2;
         if (num_samples <= 1024)
-            bn::risk_map_kernel<1024><<<blocks, bn::kRiskWaves * 64, 0, s>>>(d_mean, d_std, d_z, d_out, (int)cells, num_samples, m, confidence, seed);
+            bn::risk_map_kernel<16><<<blocks, bn::kRiskWaves * 64, 0, s>>>(d_mean, d_std, d_z, d_out, (int)cells, num_samples, m, confidence, seed);
         else if (num_samples <= 2048)
-            bn::risk_map_kernel<2048><<<blocks, bn::kRiskWaves * 64, 0, s>>>(d_mean, d_std, d_z, d_out, (int)cells, num_samples, m, confidence, seed);
+            bn::risk_map_kernel<32><<<blocks, bn::kRiskWaves * 64, 0, s>>>(d_mean, d_std, d_z, d_out, (int)cells, num_samples, m, confidence, seed);
         else
-            bn::risk_map_kernel<4096><<<blocks, bn::kRiskWaves * 64, 0, s>>>(d_mean, d_std, d_z, d_out, (int)cells, num_samples, m, confidence, seed);
+            bn::risk_map_kernel<64><<<blocks, bn::kRiskWaves * 64, 0, s>>>(d_mean, d_std, d_z, d_out, (int)cells, num_samples, m, confidence, seed);
         RISK_HIP(hipGetLastError());
     }
     if (where_out == BN_MEM_HOST) RISK_HIP(hipMemcpyAsync(out, d_out, cells * 4, hipMemcpyDeviceToHost, s));
