@@ -155,7 +155,8 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
     // ---- phase 4: rollout cost and the workgroup's softmin statistics ----
     if (wid == 0) {
         double Sd = 0.0;
-        for (int t = 0; t < T; ++t) Sd += (double)Zc[t * 64 + lane];
+#pragma unroll 16
+        for (int t = 0; t < T; ++t) Sd += (double)Zc[t * 64 + lane];          // reads batched: one LDS round trip per 16 steps
         const float cost = ((float)Sd + Zc[T * 64 + lane]) + ad[lane];                 // mppi.py:184-190
         if (active) p.cost[(size_t)b * K + k] = cost;
         const float zz = active ? (-cost) / p.lambda_ : -INFINITY;
