@@ -66,6 +66,7 @@ SYMBOLS = {
     "bn_mppi_episode_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_void_p]),
     "bn_mppi_episode_log": (C.c_int, [_H, _FP, _FP, _FP, C.POINTER(C.c_int32)]),
     "bn_mppi_dwa_solve": (C.c_int, [_H, _FP, _FP, C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.POINTER(C.c_int32)]),
+    "bn_mppi_dwa_buffers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bn_mppi_sync": (C.c_int, [_H]),
     "bn_mppi_flush": (C.c_int, [_H]),
     "bn_mppi_get_weights": (C.c_int, [_H, C.c_int32, _FP]),

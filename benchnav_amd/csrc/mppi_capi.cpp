@@ -773,6 +773,22 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
     return BN_OK;
 }
 
+int bn_mppi_dwa_buffers(bn_mppi_t *h, int32_t num_actions, const float **states_all_device, const float **costs_device,
+                        const float **weights_device)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (num_actions < 1 || num_actions > 1024) return fail(BN_ERR_INVALID, "num_actions must be in [1, 1024]");
+    const size_t B = h->p.B, NA = num_actions, T1 = h->p.T + 1;
+    const size_t n_act = B * NA * 2, n_goal = B * 2, n_X = B * NA * T1 * 3, n_c = B * NA;
+    if (!h->d_scratch || h->scratch_bytes < (n_act + n_goal + n_X + 2 * n_c + B) * 4)
+        return fail(BN_ERR_STATE, "no bn_mppi_dwa_solve with this num_actions has run");
+    const float *d_X = h->d_scratch + n_act + n_goal;          // the scratch layout of bn_mppi_dwa_solve
+    if (states_all_device) *states_all_device = d_X;
+    if (costs_device) *costs_device = d_X + n_X;
+    if (weights_device) *weights_device = d_X + n_X + n_c;
+    return BN_OK;
+}
+
 int bn_mppi_sync(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");

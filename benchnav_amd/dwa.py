@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .mppi import _planner_inputs
+from .mppi import _DevArray, _planner_inputs
 from .native import NativeMPPI
 
 
@@ -96,14 +96,17 @@ class DWA(nn.Module):
         st = state.detach().to("cpu", self._dtype)
         actions = self._generate_actions()
         sub_goal = self._select_sub_goal(st) if self.reference_path is not None else None
-        out = self._native.dwa_solve(st.numpy(), actions.numpy(), None if sub_goal is None else sub_goal.numpy())
+        out = self._native.dwa_solve(st.numpy(), actions.numpy(), None if sub_goal is None else sub_goal.numpy(), full=False)
         best = int(out["best_index"][0])
+        n = actions.shape[0]
         optimal_action_seq = actions[best].unsqueeze(0).to(self._device)
         optimal_state_seq = torch.from_numpy(out["best_states"]).to(self._device)
         self._previous_action_seq = optimal_action_seq                     # dwa.py:147
-        self._state_seq_batch = torch.from_numpy(out["states"][0]).to(self._device)
-        self._weights = torch.from_numpy(out["weights"][0]).to(self._device)
-        self._costs = torch.from_numpy(out["costs"][0]).to(self._device)
+        # the candidate batch stays on the device: views of the library's buffers, copied into tensors the caller may keep
+        xp, cp, wp = self._native.dwa_buffers(n)
+        self._state_seq_batch = torch.as_tensor(_DevArray(xp, (n, self._horizon + 1, 3)), device=self._device).clone()
+        self._costs = torch.as_tensor(_DevArray(cp, (n,)), device=self._device).clone()
+        self._weights = torch.as_tensor(_DevArray(wp, (n,)), device=self._device).clone()
         return optimal_action_seq, optimal_state_seq
 
     def get_top_samples(self) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -163,9 +163,10 @@ class NativeMPPI:
     def shard_finish_async(self, all_partials_ptr: int, total_workgroups: int):
         _capi.check(self._lib.bn_mppi_shard_finish_async(self._h, C.c_void_p(all_partials_ptr), total_workgroups))
 
-    def dwa_solve(self, states, actions, stage_goal=None):
+    def dwa_solve(self, states, actions, stage_goal=None, full: bool = True):
         """Roll out and cost constant-control candidates `actions` (B,NA,2) or (NA,2); see bn_mppi_dwa_solve.
-        Returns dict(best_action (B,2), best_states (B,T+1,3), costs, weights (B,NA), states (B,NA,T+1,3), best_index (B))."""
+        Returns dict(best_action (B,2), best_states (B,T+1,3), costs, weights (B,NA), states (B,NA,T+1,3), best_index (B));
+        full=False leaves costs / weights / states on the device (dwa_buffers) and returns the small outputs only."""
         st = _f32(states).reshape(self.B, 3)
         act = _f32(actions)
         if act.ndim == 2:
@@ -177,10 +178,19 @@ class NativeMPPI:
                    costs=np.empty((self.B, NA), np.float32), weights=np.empty((self.B, NA), np.float32),
                    states=np.empty((self.B, NA, self.T + 1, 3), np.float32), best_index=np.empty(self.B, np.int32))
         _capi.check(self._lib.bn_mppi_dwa_solve(self._h, _fp(st), _fp(act), NA, None if sg is None else _fp(sg),
-                                                _fp(out["best_action"]), _fp(out["best_states"]), _fp(out["costs"]),
-                                                _fp(out["weights"]), _fp(out["states"]),
+                                                _fp(out["best_action"]), _fp(out["best_states"]), _fp(out["costs"]) if full else None,
+                                                _fp(out["weights"]) if full else None, _fp(out["states"]) if full else None,
                                                 out["best_index"].ctypes.data_as(C.POINTER(C.c_int32))))
+        if not full:
+            for k in ("costs", "weights", "states"):
+                del out[k]
         return out
+
+    def dwa_buffers(self, num_actions: int):
+        """Device pointers (states_all, costs, weights) of the latest dwa_solve."""
+        x, c, w = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _capi.check(self._lib.bn_mppi_dwa_buffers(self._h, num_actions, C.byref(x), C.byref(c), C.byref(w)))
+        return x.value, c.value, w.value
 
     # -- device-side closed loop (PlanetaryEnv.step between solves) ------------------------------
     def env_attach(self, latent_mean, latent_std, goal_threshold: float = 1.0, delta_t: float = 0.1, seed: int = 0):

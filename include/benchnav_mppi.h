@@ -227,6 +227,10 @@ int bn_mppi_episode_log(bn_mppi_t *h, float *states_host, float *rewards_host, f
 int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actions_host, int32_t num_actions,
                       const float *stage_goal_host, float *best_action_host, float *best_states_host,
                       float *costs_host, float *weights_host, float *states_all_host, int32_t *best_index_host);
+/* Device-resident outputs of the latest bn_mppi_dwa_solve with this num_actions (valid until the next call that uses the
+ * handle's scratch memory): states_all (B,num_actions,T+1,3), costs and weights (B,num_actions). */
+int bn_mppi_dwa_buffers(bn_mppi_t *h, int32_t num_actions, const float **states_all_device, const float **costs_device,
+                        const float **weights_device);
 int bn_mppi_sync(bn_mppi_t *h);
 /* Enqueue the pending tail (if any) without waiting. */
 int bn_mppi_flush(bn_mppi_t *h);
