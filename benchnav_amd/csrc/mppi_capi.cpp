@@ -70,6 +70,7 @@ struct bn_mppi {
     int *d_idx = nullptr;
     float *d_slip_std = nullptr;     // sampled-slip mode
     float *d_ustar2[2] = {nullptr, nullptr}, *d_stats2[2] = {nullptr, nullptr};   // ticket-merge outputs by solve parity
+    std::vector<float> dwa_stage;    // host staging of bn_mppi_dwa_solve's upload
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
@@ -744,22 +745,27 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
     if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
     if (int rc = flush_tail(h)) return rc;
     const size_t B = h->p.B, NA = num_actions, T1 = h->p.T + 1;
-    // scratch layout: actions | stage goal | X | cost | w | best
-    const size_t n_act = B * NA * 2, n_goal = B * 2, n_X = B * NA * T1 * 3, n_c = B * NA;
-    const size_t floats = n_act + n_goal + n_X + 2 * n_c + B;
+    // scratch layout: actions | stage goal | X | cost | w | best | best states | states
+    const size_t n_act = B * NA * 2, n_goal = B * 2, n_X = B * NA * T1 * 3, n_c = B * NA, n_bs = B * T1 * 3;
+    const size_t floats = n_act + n_goal + n_X + 2 * n_c + B + n_bs + B * 3;
     if (int rc = ensure_scratch(h, floats * 4)) return rc;
     float *d_act = h->d_scratch, *d_goal = d_act + n_act, *d_X = d_goal + n_goal, *d_c = d_X + n_X, *d_w = d_c + n_c;
     int *d_best = reinterpret_cast<int *>(d_w + n_c);
-    BN_HIP(hipStreamSynchronize(h->stream));
-    BN_HIP(hipMemcpy(h->d_state, states_host, B * 3 * 4, hipMemcpyHostToDevice));
-    BN_HIP(hipMemcpy(d_act, actions_host, n_act * 4, hipMemcpyHostToDevice));
-    if (stage_goal_host) BN_HIP(hipMemcpy(d_goal, stage_goal_host, n_goal * 4, hipMemcpyHostToDevice));
-    else BN_HIP(hipMemcpy(d_goal, h->d_goal, n_goal * 4, hipMemcpyDeviceToDevice));          // no reference path: the goal (dwa.py:243-247)
+    float *d_bs = d_w + n_c + B, *d_st = d_bs + n_bs;
+    // one staged upload (actions | stage goal) + the states, one launch, the downloads queued behind it, one wait
+    h->dwa_stage.resize(n_act + n_goal);
+    std::memcpy(h->dwa_stage.data(), actions_host, n_act * 4);
+    if (stage_goal_host) std::memcpy(h->dwa_stage.data() + n_act, stage_goal_host, n_goal * 4);
+    BN_HIP(hipStreamSynchronize(h->stream));            // the staging vector and the scratch may still feed a previous call
+    BN_HIP(hipMemcpyAsync(d_act, h->dwa_stage.data(), (n_act + (stage_goal_host ? n_goal : 0)) * 4, hipMemcpyHostToDevice, h->stream));
+    if (!stage_goal_host) BN_HIP(hipMemcpyAsync(d_goal, h->d_goal, n_goal * 4, hipMemcpyDeviceToDevice, h->stream));   // no reference path: the goal (dwa.py:243-247)
+    BN_HIP(hipMemcpyAsync(d_st, states_host, B * 3 * 4, hipMemcpyHostToDevice, h->stream));
     bn::SolveParams p = h->p;
-    p.state = h->d_state;
-    BN_HIP(bn::launch_dwa(p, d_act, d_goal, num_actions, d_X, d_c, d_w, d_best, h->stream));
+    p.state = d_st;
+    BN_HIP(bn::launch_dwa(p, d_act, d_goal, num_actions, d_X, d_c, d_w, d_best, d_bs, h->stream));
     std::vector<int> best(B);
     BN_HIP(hipMemcpyAsync(best.data(), d_best, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (best_states_host) BN_HIP(hipMemcpyAsync(best_states_host, d_bs, n_bs * 4, hipMemcpyDeviceToHost, h->stream));
     if (costs_host) BN_HIP(hipMemcpyAsync(costs_host, d_c, n_c * 4, hipMemcpyDeviceToHost, h->stream));
     if (weights_host) BN_HIP(hipMemcpyAsync(weights_host, d_w, n_c * 4, hipMemcpyDeviceToHost, h->stream));
     if (states_all_host) BN_HIP(hipMemcpyAsync(states_all_host, d_X, n_X * 4, hipMemcpyDeviceToHost, h->stream));
@@ -767,8 +773,6 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
     for (size_t b = 0; b < B; ++b) {
         if (best_index_host) best_index_host[b] = best[b];
         if (best_action_host) std::memcpy(best_action_host + b * 2, actions_host + (b * NA + best[b]) * 2, 8);
-        if (best_states_host)
-            BN_HIP(hipMemcpy(best_states_host + b * T1 * 3, d_X + (b * NA + best[b]) * T1 * 3, T1 * 3 * 4, hipMemcpyDeviceToHost));
     }
     return BN_OK;
 }
@@ -780,7 +784,7 @@ int bn_mppi_dwa_buffers(bn_mppi_t *h, int32_t num_actions, const float **states_
     if (num_actions < 1 || num_actions > 1024) return fail(BN_ERR_INVALID, "num_actions must be in [1, 1024]");
     const size_t B = h->p.B, NA = num_actions, T1 = h->p.T + 1;
     const size_t n_act = B * NA * 2, n_goal = B * 2, n_X = B * NA * T1 * 3, n_c = B * NA;
-    if (!h->d_scratch || h->scratch_bytes < (n_act + n_goal + n_X + 2 * n_c + B) * 4)
+    if (!h->d_scratch || h->scratch_bytes < (n_act + n_goal + n_X + 2 * n_c + B + B * T1 * 3 + B * 3) * 4)
         return fail(BN_ERR_STATE, "no bn_mppi_dwa_solve with this num_actions has run");
     const float *d_X = h->d_scratch + n_act + n_goal;          // the scratch layout of bn_mppi_dwa_solve
     if (states_all_device) *states_all_device = d_X;

@@ -93,7 +93,7 @@ hipError_t launch_finish(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s);
 bool sampled_fused(const SolveParams &p);   // the sampled launch merges by ticket and carries the previous tail (LDS-window variant)
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
-                      float *w, int *best, hipStream_t s);
+                      float *w, int *best, float *best_states, hipStream_t s);
 
 hipError_t launch_env_step(const SolveParams &p, const float *actions, float *states, float *reward, int *terminated, const float *z,
                            uint64_t step, hipStream_t s);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NT) void finish_kernel(const SolveParams p)
 template <int GEO, bool LDSWIN>
 __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ actions, const float *__restrict__ stage_goal,
                            int NA, float *__restrict__ Xall, float *__restrict__ cost_out, float *__restrict__ w_out,
-                           int *__restrict__ best_out)
+                           int *__restrict__ best_out, float *__restrict__ best_states)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
@@ -113,6 +113,10 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
     for (int i = 0; i < nw; ++i) tot += red[i];
     if (active) w_out[(size_t)b * NA + tid] = e / tot;
     if (tid == 0) best_out[b] = imin;
+    // optimal_state_seq = the argmin candidate's trajectory (dwa.py:139-143): its stores are complete and visible to
+    // the workgroup since the barriers above
+    if (Xall && best_states)
+        for (int i = tid; i < (T + 1) * 3; i += nthreads) best_states[(size_t)b * (T + 1) * 3 + i] = Xall[((size_t)b * NA + imin) * (T + 1) * 3 + i];
 }
 
 // ------------------------------------------------------------------------------
@@ -273,7 +277,7 @@ hipError_t launch_finish(const SolveParams &p, hipStream_t s)
 }
 
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
-                      float *w, int *best, hipStream_t s)
+                      float *w, int *best, float *best_states, hipStream_t s)
 {
     const int threads = ((NA + 63) / 64) * 64;
     const size_t lds = sizeof(float) * ((size_t)p.WN * p.WN + 32);
@@ -281,8 +285,8 @@ hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *s
 #define BN_DWA_LAUNCH(GEO_)                                                                                          \
     do {                                                                                                             \
         if (win) { hipError_t e = ensure_lds(dwa_kernel<GEO_, true>, lds); if (e != hipSuccess) return e;           \
-                   dwa_kernel<GEO_, true><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best); } \
-        else { dwa_kernel<GEO_, false><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best); }   \
+                   dwa_kernel<GEO_, true><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best, best_states); } \
+        else { dwa_kernel<GEO_, false><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best, best_states); }   \
     } while (0)
     switch (geo_of(p)) {
     case kGeoPow2Origin0: BN_DWA_LAUNCH(kGeoPow2Origin0); break;
