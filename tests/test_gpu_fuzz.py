@@ -124,3 +124,54 @@ def test_random_sampled_slip_configuration_matches_oracle(seed):
     if np.isfinite(orc["w"]).all() and np.isfinite(orc["Ustar"]).all():
         assert m["w_abs"] <= 2e-6 or m["w_rel"] <= 1e-4, (ctx, m)
         assert m["Ustar_max"] <= 1e-5 and m["Xstar_max"] <= 5e-5, (ctx, m)
+
+
+@pytest.mark.parametrize("seed", range(300, 324))
+def test_random_dwa_configuration_matches_oracle(seed):
+    """DWA (N3): random geometry, candidate sets (ragged counts, out-of-bounds controls that the transit re-clamps),
+    states and sub-goals: trajectories, costs and the argmin bit-exact against the oracle."""
+    from oracle import oracle as O
+    from benchnav_amd import NativeMPPI
+    c = _case(seed)
+    G, T = c["G"], min(c["T"], 60)
+    rng = np.random.default_rng(seed)
+    NA = int(rng.choice([1, 7, 64, 100, 130, 400]))
+    acts = np.stack([rng.uniform(-0.3, 1.3, NA), rng.uniform(-1.5, 1.5, NA)], 1).astype(np.float32)
+    sub = None if rng.random() < 0.4 else np.array([rng.uniform(*c["xl"]), rng.uniform(*c["yl"])], np.float32)
+    p = O.make_params(64, T, G, c["res"], c["goal"], thr=c["thr"], u_min=c["u_min"], u_max=c["u_max"], x_limits=c["xl"], y_limits=c["yl"],
+                      trig=O.TRIG_SPEC)
+    orc = O.dwa(p, c["R"], c["state"], acts, sub)
+    with NativeMPPI(horizon=T, num_samples=64, grid_size=G, resolution=c["res"], x_limits=list(c["xl"]), y_limits=list(c["yl"]),
+                    u_min=c["u_min"], u_max=c["u_max"], stuck_threshold=c["thr"], lds_window=c["window"]) as pl:
+        pl.set_map(c["R"]); pl.set_goal(c["goal"])
+        out = pl.dwa_solve(c["state"], acts, sub)
+    assert np.array_equal(out["states"][0], orc["X"]) and np.array_equal(out["costs"][0], orc["cost"]), (seed, NA, T, G)
+    assert int(out["best_index"][0]) == orc["best"] and np.array_equal(out["best_states"][0], orc["X"][orc["best"]])
+    if np.isfinite(orc["w"]).all():
+        assert np.abs(out["weights"][0] - orc["w"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("seed", range(400, 416))
+def test_random_risk_map_matches_oracle(seed):
+    """Risk-map precompute (N1): random maps, sample counts (not multiples of 64, past 1024 and 2048) and confidence
+    levels incl. 0 and 1, injected draws: VaR bit-exact (selection + lerp), CVaR within summation order."""
+    import torch
+    from oracle import risk_oracle as RO
+    from benchnav_amd.risk import infer_risk_map
+    rng = np.random.default_rng(seed)
+    G = int(rng.choice([3, 8, 17, 32]))
+    n = int(rng.choice([2, 3, 63, 64, 65, 200, 1000, 1024, 1025, 2048, 2500, 4096]))
+    q = float(rng.choice([0.0, 1.0, 0.5, 0.9, 0.975, rng.random()]))
+    mean = (rng.random((G, G)) * rng.choice([0.5, 1.0, 5.0]) - rng.choice([0.0, 0.3])).astype(np.float32)
+    std = (rng.random((G, G)) * rng.choice([0.0, 0.1, 1.0])).astype(np.float32)
+    z = rng.standard_normal((n, G, G)).astype(np.float32)
+    if rng.random() < 0.3:
+        z[: n // 2] = z[n // 2: n // 2 * 2]                       # ties
+    for metric in ("var", "cvar"):
+        got = infer_risk_map(torch.from_numpy(mean), torch.from_numpy(std), metric, q, num_samples=n, z=torch.from_numpy(z)).cpu().numpy()
+        want = RO.infer_risk_map(mean, std, metric, q, z)
+        if metric == "var":
+            assert np.array_equal(got, want), (seed, G, n, q)
+        else:
+            both_nan = np.isnan(got) & np.isnan(want)
+            assert (both_nan | (np.abs(got - want) <= 2e-6 * np.maximum(1, np.abs(want)))).all(), (seed, G, n, q)
