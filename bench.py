@@ -4,41 +4,47 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[1] -- a single 256x256 map, K=1024 rollouts,
-T=50 steps, one planning instance per GPU.  A "step" is one complete MPPI solve (noise sampling,
-K x T rollout with per-step map lookups, stage/terminal/control costs, softmin weights, weighted
-control reduction, optimal-sequence rollout, warm-start update) -- the work of the reference's
-MPPI.forward (mppi.py:130-219).  Successive steps are warm-started from the previous U*, so they
-form a dependent chain exactly like the reference's closed loop; the planner state is held fixed
-(open-loop variant).  Inputs (map, goal, state, mean) are resident in HBM before
-the timed region.  With N > 1 every rank plans its own map seed (instance sharding, no data-path
-collective); RCCL is used only to agree on the slowest rank's time.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (one process per GPU under
+torch.distributed.run, RCCL = backend "nccl"); under an external launcher WORLD_SIZE must equal N.  Fewer than N visible
+GPUs is an error.
+
+Workload (config.workload): BASELINE.json configs[1] -- a single 256x256 map, K=1024 rollouts, T=50 steps, one planning
+instance per GPU.  A "step" is one complete MPPI solve (noise sampling, K x T rollout with per-step map lookups,
+stage/terminal/control costs, softmin weights, weighted control reduction, optimal-sequence rollout, warm-start update)
+-- the work of the reference's MPPI.forward (mppi.py:130-219).  Successive steps are warm-started from the previous U*,
+so they form a dependent chain exactly like the reference's closed loop; the planner state is held fixed (open-loop
+variant).  Inputs (map, goal, state, mean) are resident in HBM before the timed region.  With N > 1 every
+rank plans its own map seed (instance sharding, no data-path collective); RCCL carries only the barrier around the timed
+region and the final gather of the per-rank times.
+
+Timing: exactly K steps between barrier + synchronize on both sides, max over ranks -- repeated (`repeats`) so that a
+K of 20 is not a 0.3 ms sample; `ms_per_step` / `value` are the MEDIAN repeat, the min is reported beside it.
 
 Extra objects on the line:
-  roofline      dominant kernel (rollout) against the HBM roofline, algorithmic bytes per launch
-                over the kernel's mean duration measured with HIP events on the launch stream
-  cpu_baseline  the PyTorch-CPU port of the reference (oracle/torch_port.py) timed on this host
-  batched       64 instances per launch (config 4's per-node batch on one GPU): the regime where
-                the HBM roofline is meaningful
+  roofline      dominant kernel (rollout) against the HBM roofline: algorithmic bytes per launch over the kernel's mean
+                launch-to-launch duration, from a HIP event pair around the K launches of the SAME timed region on the
+                launch stream (so kernel_ms <= ms_per_step by construction)
+  cpu_baseline  the PyTorch-CPU port of the reference (oracle/torch_port.py) timed on this host (N = 1 only)
+  batched       64 instances per launch (config 4's per-node batch on one GPU): the regime where the HBM roofline is
+                meaningful; with its lean-mode line (no trajectory dump) beside the full-API one
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from benchnav_amd import NativeMPPI, _capi, synth  # noqa: E402
-
 G, K, T, RES = 256, 1024, 50, 0.5
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
+MIN_TIMED_STEPS = 2000         # repeats = ceil(MIN_TIMED_STEPS / steps)
 
 
 def parse():
@@ -51,63 +57,387 @@ def parse():
     ap.add_argument("--batched-instances", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher check without a GPU: spawn the ranks, rendezvous, gather, print who took part; no planning")
     return ap.parse_args()
 
 
-def make_planner(inst, dev, B=1, profile=False, shared_map=True):
-    pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, shared_map=shared_map,
-                    device_id=dev, profile=profile, stream=torch.cuda.current_stream().cuda_stream)
-    pl.set_map(inst.risk.numpy())
-    pl.set_goal(inst.goal.numpy())
-    return pl
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def timed_solves(pl, state_dev, eps_ring, kind, steps, sync):
-    """Enqueue `steps` dependent solves (software-pipelined: one launch each), then the tail of the last
-    one; returns wall seconds between the two syncs.  Every solve's U*, X* and weights are written."""
-    sync()
-    t0 = time.perf_counter()
-    if eps_ring is None:
-        pl.solve_n_async_device(steps, state_dev.data_ptr())
-    else:                                            # eps_ring: one contiguous tensor (ring, ...), cycled per solve
-        pl.solve_n_async_device(steps, state_dev.data_ptr(), eps_ring.data_ptr(), kind, eps_ring.shape[0],
-                                eps_ring[0].numel())
-    if os.environ.get("BENCH_DEBUG") and steps >= 1000:
-        print(f"[timed] enqueue of {steps} launches returned after {(time.perf_counter() - t0) / steps * 1e6:.2f} us/launch", file=sys.stderr)
-    pl.flush()
-    sync()
-    return time.perf_counter() - t0
+def spawn_ranks(a) -> int:
+    """`bench.py --gpus N` without a launcher: become the launcher (one process per GPU, torch.distributed.run)."""
+    if not a.rehearse:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus and not os.environ.get("BENCH_SHARE_GPU"):
+            print(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible; one process per GPU needs {a.gpus}", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
-def settle(make, state_dev, eps_ring, kind, warmup, sync_local, tries=3):
-    """Untimed: build the planner, run the warm-up steps, and make sure the queue is not in the
-    rare slow-dispatch state seen on some boxes (milliseconds between back-to-back launches): if a
-    100-step probe is >5x slower than the best probe seen, rebuild the handle and try again."""
-    best = None
-    for _ in range(tries):
-        pl = make()
-        timed_solves(pl, state_dev, eps_ring, kind, max(warmup, 1), sync_local)
-        probes = [timed_solves(pl, state_dev, eps_ring, kind, 100, sync_local) / 100 for _ in range(3)]
-        p = min(probes)
-        if os.environ.get("BENCH_DEBUG"):
-            print(f"[settle] probes us/step: {[round(x * 1e6, 2) for x in probes]}", file=sys.stderr)
-        best = p if best is None else min(best, p)
-        if p <= 5 * best and p < 2e-3:
-            return pl
-        pl.close()
-    return make()
+def host_cpu():
+    model, phys = "unknown", set()
+    try:
+        pid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                phys.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": os.cpu_count(), "physical_cores": len(phys) or None}
 
 
-def cpu_baseline(inst, seconds):
+def main():
+    a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: they must agree")
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
+    if a.rehearse:
+        return rehearse(rank, world, local, backend)
+
+    import numpy as np
+    import torch
+    from benchnav_amd import NativeMPPI, _capi, synth
+    from benchnav_amd.sharding import gather_times
+
+    host_threads = torch.get_num_threads()
+    # The GPU legs need no host arithmetic: keep torch's intra-op pool out of the process until the CPU baseline leg
+    # (spinning pool threads next to the HIP runtime's submission thread were seen to stretch a timed loop 2x).
+    torch.set_num_threads(1)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the MPPI planner has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    shared_gpu = False
+    if local >= ndev:
+        if not os.environ.get("BENCH_SHARE_GPU"):
+            raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({ndev} visible); one process per GPU needs {world}")
+        shared_gpu = True                              # 1-GPU box rehearsing the N > 1 path (flagged in the output)
+    dev = local % ndev
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = torch.device("cuda", dev) if (dist is not None and backend == "nccl") else None
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream()
+
+    def make_planner(inst, B=1, **kw):
+        pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=dev,
+                        stream=stream.cuda_stream, **kw)
+        pl.set_map(inst.risk.numpy())
+        pl.set_goal(inst.goal.numpy())
+        return pl
+
+    def timed_solves(pl, state_dev, eps_ring, kind, steps, sync_):
+        """Enqueue `steps` dependent solves (software-pipelined: one launch each), then the tail of the last one.
+        Returns (wall seconds between the two syncs, milliseconds between HIP events placed on the launch stream before
+        the first and after the last launch).  Every solve's U*, X* and weights are written."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        if eps_ring is None:
+            pl.solve_n_async_device(steps, state_dev.data_ptr())
+        else:                                            # eps_ring: one contiguous tensor (ring, ...), cycled per solve
+            pl.solve_n_async_device(steps, state_dev.data_ptr(), eps_ring.data_ptr(), kind, eps_ring.shape[0], eps_ring[0].numel())
+        e1.record(stream)
+        pl.flush()
+        sync_()
+        wall = time.perf_counter() - t0
+        return wall, e0.elapsed_time(e1)
+
+    def settle(make, state_dev, eps_ring, kind, warmup, tries=3):
+        """Untimed: build the planner, run the warm-up steps, and make sure the queue is not in the rare slow-dispatch
+        state seen on some boxes (milliseconds between back-to-back launches): if a 100-step probe is >5x slower than the
+        best probe seen, rebuild the handle and try again."""
+        best = None
+        for _ in range(tries):
+            pl = make()
+            timed_solves(pl, state_dev, eps_ring, kind, max(warmup, 1), torch.cuda.synchronize)
+            probes = [timed_solves(pl, state_dev, eps_ring, kind, 100, torch.cuda.synchronize)[0] / 100 for _ in range(3)]
+            p = min(probes)
+            if os.environ.get("BENCH_DEBUG"):
+                print(f"[settle] probes us/step: {[round(x * 1e6, 2) for x in probes]}", file=sys.stderr)
+            best = p if best is None else min(best, p)
+            if p <= 5 * best and p < 2e-3:
+                return pl
+            pl.close()
+        return make()
+
+    def repeated(pl, state_dev, eps_ring, kind, steps, sync_, repeats):
+        walls, evs = [], []
+        for _ in range(repeats):
+            w, e = timed_solves(pl, state_dev, eps_ring, kind, steps, sync_)
+            walls.append(w)
+            evs.append(e)
+        return walls, evs
+
+    inst = synth.make_instance(G, seed=rank, resolution=RES)       # independent map seed per rank
+    state_dev = inst.start.cuda()
+    if a.noise == "injected":
+        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        eps_ring = torch.randn(8, T, 2, K, device="cuda", generator=gen)
+        kind = _capi.BN_NOISE_DEVICE_T2K
+    else:
+        eps_ring, kind = None, _capi.BN_NOISE_PHILOX
+    injected = a.noise == "injected"
+
+    # host-side instance generation for the batched leg happens before any timing (no idle gap later)
+    extras = rank == 0 and world == 1 and not a.no_extras
+    batched_insts = None
+    if extras and not a.no_batched:
+        batched_insts = [synth.make_instance(G, seed=s, resolution=RES, jitter=True) for s in range(a.batched_instances)]
+
+    # ---- headline: dependent solves of one instance per GPU, K steps x `repeats` ------------------------------
+    repeats = max(1, min(200, -(-MIN_TIMED_STEPS // max(a.steps, 1))))
+    pl = settle(lambda: make_planner(inst), state_dev, eps_ring, kind, a.warmup)
+    walls, evs = repeated(pl, state_dev, eps_ring, kind, a.steps, sync, repeats)
+    alg_bytes = pl.algorithmic_bytes(injected_noise=injected)
+    sustained = None
+    if rank == 0 and world == 1 and a.steps < 1000:      # the steady-state figure next to a short contract run
+        w_s, e_s = timed_solves(pl, state_dev, eps_ring, kind, 3000, torch.cuda.synchronize)
+        sustained = {"steps": 3000, "value": 3000 / w_s, "ms_per_step": w_s / 3000 * 1e3, "kernel_ms": e_s / 3000}
+    pl.close()
+    per_rank = gather_times(walls, coll_dev)                       # (world, repeats): the only data exchange, 8 B x repeats per rank
+    job = per_rank.max(dim=0).values                               # the slowest rank bounds every repeat
+    med = float(job.median())
+    r_med = int((job - med).abs().argmin())
+    value = world * a.steps / med
+    names = [None] * world
+    me = f"rank {rank}: cuda:{dev} {torch.cuda.get_device_name(dev)}"
+    if dist is not None:
+        dist.all_gather_object(names, me)
+    else:
+        names = [me]
+
+    out = None
+    if rank == 0:
+        kernel_ms = evs[r_med] / a.steps                            # same handle, same repeat as ms_per_step
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, see profiles/README.md
+        tj = {}
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+            except Exception:
+                tj = {}
+        traffic = tj.get(f"rollout_{a.noise}_B1")
+        traffic_src = tj.get("collected") if traffic is not None else None
+        # measured device-to-device copy rate of this box (1 GiB read + 1 GiB written per pass): the practical HBM ceiling
+        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * src.numel() * 4 / (time.perf_counter() - t0) / 1e9
+        del src, dst
+        out = {
+            "metric": "MPPI solve-steps/sec (K=1024,T=50,256x256 map)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": med / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": repeats, "ms_per_step_min": float(job.min()) / a.steps * 1e3, "ms_per_step_max": float(job.max()) / a.steps * 1e3,
+            "world_size": world, "devices": names,
+            "per_rank_solves": [a.steps] * world, "per_rank_seconds": [float(x) for x in per_rank[:, r_med]],
+            "host_cpu": host_cpu(),
+            "config": {"workload": "BASELINE configs[1]: single 256x256 map, K=1024, T=50, one instance per GPU, "
+                                   "dependent warm-started solves, fixed state",
+                       "grid": G, "num_samples": K, "horizon": T, "resolution": RES, "instances_per_gpu": 1,
+                       "noise": "philox in-kernel (sampling inside the timed region)" if a.noise == "philox"
+                                else "injected eps (T,2,K) resident in HBM",
+                       "parallelism": f"instance sharding x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
+                         "kernel": "bn::rollout_kernel (5 role-specialised waves per 64 rollouts; in the pipelined "
+                                   "mode it also carries the previous solve's merge + tail workgroup)",
+                         "kernel_ms": kernel_ms, "kernel_ms_source": "HIP event pair on the launch stream around the K launches of the "
+                                                                     "median repeat (launch-to-launch mean)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": a.steps,
+                         "note": "single-instance solve = 16 workgroups x a 50-step serial chain (~5.2 us of dependent instructions): "
+                                 "latency-bound; at 0.9 MB per solve one launch boundary (~1.4 us) alone caps a launch-per-solve design "
+                                 "at ~7 % of HBM peak and the chain at ~2 %; the batched object is the HBM-relevant regime (DESIGN.md 6)"},
+        }
+        if shared_gpu or backend != "nccl":
+            out["rehearsal"] = f"ranks shared {ndev} GPU(s), backend {backend}: not a scaling measurement"
+        if sustained:
+            out["sustained"] = sustained
+
+    if extras:
+        def leg(pl_, st_, ring_, n_):
+            timed_solves(pl_, st_, ring_, kind, 30, torch.cuda.synchronize)
+            best = None
+            for _ in range(3):
+                w, e = timed_solves(pl_, st_, ring_, kind, n_, torch.cuda.synchronize)
+                if best is None or w < best[0]:
+                    best = (w, e)
+            return best[0] / n_, best[1] / n_              # seconds per launch (wall), ms per launch (events)
+
+        def roof(bytes_, ms, traffic_key):
+            return {"bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tj.get(traffic_key), "kernel_ms": ms,
+                    "algorithmic_bytes_per_launch": bytes_}
+
+        # ---- lean mode, single instance: no trajectory dump (SURVEY 8d lean formula) ---------------------------
+        pll = make_planner(inst, lean=True)
+        s_l, ms_l = leg(pll, state_dev, eps_ring, max(500, a.steps))
+        by_l = pll.algorithmic_bytes(injected_noise=injected)
+        pll.close()
+        out["lean"] = {"value": 1.0 / s_l, "unit": "solves/s", "ms_per_step": s_l * 1e3,
+                       "note": "BN_FLAG_LEAN: _state_seq_batch not materialised; get_top_samples re-rolls the requested rows bit-identically",
+                       "roofline": roof(by_l, ms_l, f"rollout_{a.noise}_B1_lean")}
+        # ---- batched: 64 instances per launch on this GPU (HBM-relevant regime) -------------------
+        if not a.no_batched:
+            B = a.batched_instances
+            insts = batched_insts
+            states = torch.stack([it.start for it in insts]).cuda()
+            ring = torch.randn(2, B, T, 2, K, device="cuda") if injected else None
+            nb = max(100, a.steps // 10)
+            res_b = {}
+            for lean in (False, True):
+                plb = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=dev,
+                                 stream=stream.cuda_stream, lean=lean)
+                for b, it in enumerate(insts):
+                    plb.set_map(it.risk.numpy(), b)
+                    plb.set_goal(it.goal.numpy(), b)
+                s_b, ms_b = leg(plb, states, ring, nb)
+                bytes_b = plb.algorithmic_bytes(injected_noise=injected) * B
+                plb.close()
+                res_b[lean] = {"value": B / s_b, "unit": "solves/s", "ms_per_launch": s_b * 1e3,
+                               "roofline": roof(bytes_b, ms_b, f"rollout_{a.noise}_B{B}" + ("_lean" if lean else ""))}
+            # a launch large enough for the one-wave throughput kernel (auto-selected above ~1500 workgroups)
+            BL = 256
+            large = {}
+            for lean in (False, True):
+                plw = make_planner(inst, B=BL, shared_map=True, lean=lean)
+                stl = torch.stack([inst.start] * BL).cuda()
+                s_w, ms_w = leg(plw, stl, None, max(30, a.steps // 40))
+                bytes_w = plw.algorithmic_bytes(injected_noise=False) * BL
+                plw.close()
+                large[lean] = {"instances_per_launch": BL, "value": BL / s_w, "unit": "solves/s", "ms_per_launch": s_w * 1e3,
+                               "kernel": "bn::rollout_wave_kernel (one wave per 64 rollouts)",
+                               "roofline": roof(bytes_w, ms_w, f"rollout_wave_{a.noise}_B{BL}" + ("_lean" if lean else ""))}
+            large[False]["lean"] = large[True]
+            out["batched"] = dict(res_b[False], instances_per_launch=B, lean=res_b[True], large_batch=large[False])
+        # ---- closed loop on the device: solve -> PlanetaryEnv.step -> solve ..., one launch per control step ----
+        plc = make_planner(inst)
+        plc.env_attach(inst.risk.numpy(), np.full((G, G), 0.05, np.float32))      # latent slip ~ N(risk, 0.05)
+        n_cl = max(a.steps, 1000)
+        plc.episode(200, inst.start.numpy())
+        t0 = time.perf_counter()
+        states, rewards, done = plc.episode(n_cl, inst.start.numpy())
+        elc = time.perf_counter() - t0
+        plc.close()
+        out["closed_loop"] = {"value": n_cl / elc, "unit": "control steps/s", "us_per_step": elc / n_cl * 1e6,
+                              "instances": 1, "steps": n_cl,
+                              "distance_to_goal_m": [float(np.linalg.norm(states[0, 0, :2] - inst.goal.numpy())),
+                                                     float(np.linalg.norm(states[-1, 0, :2] - inst.goal.numpy()))],
+                              "note": "bn_mppi_episode_async: state advanced on the device by the observation-mode "
+                                      "transit with sampled slip (planetary_env.py:189-219); includes the final log copy"}
+        # ---- BASELINE config 3: K=8192, T=50, slip sampled per lookup from Normal(mean, std) (Philox in-kernel) ----
+        K3 = 8192
+        pl3 = NativeMPPI(horizon=T, num_samples=K3, grid_size=G, resolution=RES, device_id=dev, sampled_slip=True, stream=stream.cuda_stream)
+        pl3.set_map(inst.risk.numpy()); pl3.set_slip_std(synth.slip_std_map(G, seed=0).numpy()); pl3.set_goal(inst.goal.numpy())
+        s3, ms3 = leg(pl3, state_dev, None, max(100, a.steps // 10))
+        pl3.close()
+        # algorithmic bytes (SURVEY.md 8d with in-kernel draws): mean + std maps, X, cost + weights, mean/state/U*/X*
+        bytes3 = 8 * G * G + 12 * K3 * (T + 1) + 8 * K3 + 28 * T + 24
+        out["sampled_slip"] = {"workload": f"BASELINE configs[2]: mppi_solve K={K3} T={T} map={G}x{G}, slip ~ Normal(mean, std)[cell] drawn per lookup",
+                               "value": 1.0 / s3, "unit": "solves/s", "us_per_solve": s3 * 1e6, "draws_per_solve": K3 * (2 * T + 1) + T,
+                               "roofline": dict(roof(bytes3, ms3, f"rollout_sampled_K{K3}"),
+                                                kernel="bn::rollout_sampled_kernel (one launch per solve: rollouts, ticket merge, previous tail)")}
+        # ---- BASELINE configs[4] on one GPU: 512x512 map, K=16384, T=100 (LDS-tiled 43x43 window) ----
+        K5, T5, G5 = 16384, 100, 512
+        inst5 = synth.make_instance(G5, seed=0, resolution=RES)
+        pl5 = NativeMPPI(horizon=T5, num_samples=K5, grid_size=G5, resolution=RES, device_id=dev, stream=stream.cuda_stream)
+        pl5.set_map(inst5.risk.numpy()); pl5.set_goal(inst5.goal.numpy())
+        st5 = inst5.start.cuda()
+        s5, ms5 = leg(pl5, st5, None, max(50, a.steps // 20))
+        bytes5 = pl5.algorithmic_bytes(injected_noise=False)
+        pl5.close()
+        out["config5_one_gpu"] = {"workload": f"BASELINE configs[4] on one GPU: mppi_solve K={K5} T={T5} map={G5}x{G5}",
+                                  "value": 1.0 / s5, "unit": "solves/s", "us_per_solve": s5 * 1e6,
+                                  "roofline": roof(bytes5, ms5, f"rollout_K{K5}_T{T5}_G{G5}")}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds, host_threads)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def rehearse(rank, world, local, backend):
+    """Launcher check (CPU test): the ranks meet, exchange who they are and one timing vector, rank 0 reports.
+    No planner is created and no `value` is printed: this is not a measurement and not a CPU path of the product."""
+    import torch
+    import torch.distributed as dist
+    from benchnav_amd.sharding import gather_times
+    if world > 1:
+        dist.init_process_group(backend if backend != "nccl" or torch.cuda.is_available() else "gloo")
+    who = [None] * world
+    me = {"rank": rank, "local_rank": local, "pid": os.getpid()}
+    if world > 1:
+        dist.all_gather_object(who, me)
+    else:
+        who = [me]
+    per_rank = gather_times([0.001 * (rank + 1), 0.002 * (rank + 1)], None)
+    if world > 1:
+        dist.barrier()
+        used = dist.get_backend()
+        dist.destroy_process_group()
+    else:
+        used = None
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "world_size": world, "backend": used, "ranks": who,
+                          "gathered_shape": list(per_rank.shape), "slowest_per_repeat": [float(x) for x in per_rank.max(dim=0).values]}))
+
+
+def cpu_baseline(inst, seconds, default_threads):
     """The reference's CPU path, as ported in oracle/torch_port.py, on this box's host cores.
     The path is dispatch-bound (~19k ATen calls per solve), so it is timed with 1 thread and with
     torch's default thread count and the faster of the two is reported."""
+    import numpy as np
+    import torch
     from oracle import torch_port as TP
     pb = TP.Problem(risk=inst.risk, goal=inst.goal, grid_size=G, resolution=RES, x_limits=(0.0, G * RES),
                     y_limits=(0.0, G * RES), sigmas=torch.tensor([0.5, 0.5]), lambda_=0.5, stuck_threshold=0.3,
                     u_min=torch.tensor([0.0, -1.0]), u_max=torch.tensor([1.0, 1.0]))
-    default_threads = HOST_THREADS
     runs = {}
     for threads in sorted({1, default_threads}):
         torch.set_num_threads(threads)
@@ -126,10 +456,11 @@ def cpu_baseline(inst, seconds):
     torch.set_num_threads(default_threads)
     best = max(runs, key=lambda k_: runs[k_][0])
     rate, n, el = runs[best]
+    cpu = host_cpu()
     out = {"value": rate, "unit": "solves/s", "cores": best, "kind": "port",
            "sample": f"{n} warm-started solves of the same workload (K={K}, T={T}, {G}x{G} map) in {el:.1f} s, "
                      f"PyTorch-CPU port of mppi.py:130-219 (oracle/torch_port.py), torch {torch.__version__}, "
-                     f"{os.cpu_count()} host cpus",
+                     f"{cpu['model']}, {cpu['logical_cpus']} logical cpus",
            "by_threads": {str(k_): v[0] for k_, v in runs.items()}}
     # the scalar C oracle on one core, for scale (a stronger CPU implementation than the reference's)
     try:
@@ -146,232 +477,6 @@ def cpu_baseline(inst, seconds):
     except Exception as e:  # the C oracle is optional for the baseline leg
         out["c_oracle_error"] = str(e)
     return out
-
-
-HOST_THREADS = torch.get_num_threads()
-
-
-def main():
-    a = parse()
-    # The GPU legs need no host arithmetic: keep torch's intra-op pool out of the process until the CPU baseline leg
-    # (spinning pool threads next to the HIP runtime's submission thread were seen to stretch a timed loop 2x).
-    torch.set_num_threads(1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the MPPI planner has no CPU fallback")
-    local = local % torch.cuda.device_count()      # identity on a full node; lets a 1-GPU box rehearse the N > 1 path
-    torch.cuda.set_device(local)
-    dist = None
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    inst = synth.make_instance(G, seed=rank, resolution=RES)       # independent map seed per rank
-    state_dev = inst.start.cuda()
-    if a.noise == "injected":
-        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-        eps_ring = torch.randn(8, T, 2, K, device="cuda", generator=gen)
-        kind = _capi.BN_NOISE_DEVICE_T2K
-    else:
-        eps_ring, kind = None, _capi.BN_NOISE_PHILOX
-
-    # host-side instance generation for the batched leg happens before any timing (no idle gap later)
-    batched_insts = None
-    if rank == 0 and world == 1 and not a.no_batched:
-        batched_insts = [synth.make_instance(G, seed=s, resolution=RES, jitter=True) for s in range(a.batched_instances)]
-
-    # ---- headline: dependent solves of one instance per GPU -------------------------------------
-    pl = settle(lambda: make_planner(inst, local), state_dev, eps_ring, kind, a.warmup, torch.cuda.synchronize)
-    elapsed = timed_solves(pl, state_dev, eps_ring, kind, a.steps, sync)
-    from benchnav_amd.sharding import gather_throughput
-    job = gather_throughput(a.steps, elapsed,
-                            device=torch.device("cuda", local) if (dist is not None and backend == "nccl") else None)
-    elapsed = job["max_seconds"]                                   # the only collective: 16 bytes per rank
-    value = job["total_solves"] / elapsed
-    alg_bytes = pl.algorithmic_bytes(injected_noise=(a.noise == "injected"))
-    pl.close()
-
-    out = None
-    if rank == 0:
-        # ---- roofline of the dominant kernel: HIP events around every launch, same K steps -------
-        plp = settle(lambda: make_planner(inst, local, profile=True), state_dev, eps_ring, kind, min(a.warmup, 50),
-                     torch.cuda.synchronize)
-        plp.kernel_ms()
-        el_prof = timed_solves(plp, state_dev, eps_ring, kind, a.steps, torch.cuda.synchronize)
-        r_ms, f_ms, n_prof = plp.kernel_ms()
-        plp.close()
-        achieved = alg_bytes / (r_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, see profiles/README.md
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"rollout_{a.noise}_B1")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "MPPI solve-steps/sec (K=1024,T=50,256x256 map)", "value": value, "unit": "solves/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: single 256x256 map, K=1024, T=50, one instance per GPU, "
-                                   "dependent warm-started solves, fixed state",
-                       "grid": G, "num_samples": K, "horizon": T, "resolution": RES, "instances_per_gpu": 1,
-                       "noise": "philox in-kernel (sampling inside the timed region)" if a.noise == "philox"
-                                else "injected eps (T,2,K) resident in HBM",
-                       "parallelism": f"instance sharding x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bn::rollout_kernel (5 role-specialised waves per 64 rollouts; in the pipelined "
-                                   "mode it also carries the previous solve's merge + tail workgroup)",
-                         "kernel_ms": r_ms, "finish_kernel_ms": f_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_prof,
-                         "ms_per_step_with_events": el_prof / a.steps * 1e3,
-                         "note": "single-instance solve is a 2xT-step dependent chain: latency-bound, see DESIGN.md"},
-        }
-        # ---- batched: 64 instances per launch on this GPU (HBM-relevant regime) -------------------
-        if not a.no_batched and world == 1:
-            B = a.batched_instances
-            insts = batched_insts
-
-            def make_batched():
-                plb_ = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=local,
-                                  profile=True, stream=torch.cuda.current_stream().cuda_stream)
-                for b, it in enumerate(insts):
-                    plb_.set_map(it.risk.numpy(), b)
-                    plb_.set_goal(it.goal.numpy(), b)
-                return plb_
-            states = torch.stack([it.start for it in insts]).cuda()
-            if a.noise == "injected":
-                ring = torch.randn(2, B, T, 2, K, device="cuda")
-            else:
-                ring = None
-            nb = max(50, a.steps // 10)
-            plb = settle(make_batched, states, ring, kind, 50, torch.cuda.synchronize)
-            plb.kernel_ms()
-            elb = timed_solves(plb, states, ring, kind, nb, torch.cuda.synchronize)
-            rb, fb, _ = plb.kernel_ms()
-            bytes_b = plb.algorithmic_bytes(injected_noise=(a.noise == "injected")) * B
-            plb.close()
-            traffic_b = None
-            if os.path.exists(tpath):
-                try:
-                    traffic_b = json.load(open(tpath)).get(f"rollout_{a.noise}_B{B}")
-                except Exception:
-                    traffic_b = None
-            # a launch large enough for the one-wave throughput kernel (auto-selected above ~1500 workgroups)
-            BL = 256
-            pll = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=BL, shared_map=True, device_id=local,
-                             profile=True, stream=torch.cuda.current_stream().cuda_stream)
-            pll.set_map(inst.risk.numpy()); pll.set_goal(inst.goal.numpy())
-            stl = torch.stack([inst.start] * BL).cuda()
-            timed_solves(pll, stl, None, kind, 30, torch.cuda.synchronize)
-            pll.kernel_ms()
-            nl = max(30, a.steps // 40)
-            ell = timed_solves(pll, stl, None, kind, nl, torch.cuda.synchronize)
-            rl, _, _ = pll.kernel_ms()
-            bytes_l = pll.algorithmic_bytes(injected_noise=False) * BL
-            pll.close()
-            traffic_l = None
-            if os.path.exists(tpath):
-                try:
-                    traffic_l = json.load(open(tpath)).get(f"rollout_wave_{a.noise}_B{BL}")
-                except Exception:
-                    traffic_l = None
-            large = {"instances_per_launch": BL, "traffic": traffic_l, "value": BL * nl / ell, "unit": "solves/s", "ms_per_launch": ell / nl * 1e3,
-                     "kernel": "bn::rollout_wave_kernel (one wave per 64 rollouts)", "kernel_ms": rl,
-                     "hbm_frac": bytes_l / (rl * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_l}
-            out["batched"] = {"instances_per_launch": B, "value": B * nb / elb, "unit": "solves/s", "large_batch": large,
-                              "ms_per_launch": elb / nb * 1e3,
-                              "roofline": {"bound": "hbm", "achieved": bytes_b / (rb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                           "unit": "GB/s", "frac": bytes_b / (rb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "traffic": traffic_b, "kernel_ms": rb, "finish_kernel_ms": fb,
-                                           "algorithmic_bytes_per_launch": bytes_b}}
-        # ---- closed loop on the device: solve -> PlanetaryEnv.step -> solve ..., one launch per control step ----
-        if world == 1:
-            plc = make_planner(inst, local)
-            plc.env_attach(inst.risk.numpy(), np.full((G, G), 0.05, np.float32))      # latent slip ~ N(risk, 0.05)
-            plc.episode(min(a.warmup, 200), inst.start.numpy())
-            t0 = time.perf_counter()
-            states, rewards, done = plc.episode(a.steps, inst.start.numpy())
-            elc = time.perf_counter() - t0
-            plc.close()
-            out["closed_loop"] = {"value": a.steps / elc, "unit": "control steps/s", "us_per_step": elc / a.steps * 1e6,
-                                  "instances": 1, "steps": a.steps,
-                                  "distance_to_goal_m": [float(np.linalg.norm(states[0, 0, :2] - inst.goal.numpy())),
-                                                         float(np.linalg.norm(states[-1, 0, :2] - inst.goal.numpy()))],
-                                  "note": "bn_mppi_episode_async: state advanced on the device by the observation-mode "
-                                          "transit with sampled slip (planetary_env.py:189-219); includes the final log copy"}
-        # ---- BASELINE config 3: K=8192, T=50, slip sampled per lookup from Normal(mean, std) (Philox in-kernel) ----
-        if world == 1:
-            K3 = 8192
-            pl3 = NativeMPPI(horizon=T, num_samples=K3, grid_size=G, resolution=RES, device_id=local, profile=True,
-                             sampled_slip=True, stream=torch.cuda.current_stream().cuda_stream)
-            pl3.set_map(inst.risk.numpy()); pl3.set_slip_std(synth.slip_std_map(G, seed=0).numpy()); pl3.set_goal(inst.goal.numpy())
-            n3 = max(50, a.steps // 10)
-            timed_solves(pl3, state_dev, None, kind, 50, torch.cuda.synchronize)
-            pl3.kernel_ms()
-            el3 = timed_solves(pl3, state_dev, None, kind, n3, torch.cuda.synchronize)
-            r3, f3, _ = pl3.kernel_ms()
-            pl3.close()
-            # algorithmic bytes (SURVEY.md 8d with in-kernel draws): mean + std maps, X, cost + weights, mean/state/U*/X*
-            bytes3 = 8 * G * G + 12 * K3 * (T + 1) + 8 * K3 + 28 * T + 24
-            traffic3 = None
-            if os.path.exists(tpath):
-                try:
-                    traffic3 = json.load(open(tpath)).get(f"rollout_sampled_K{K3}")
-                except Exception:
-                    traffic3 = None
-            out["sampled_slip"] = {"workload": f"BASELINE configs[2]: mppi_solve K={K3} T={T} map={G}x{G}, slip ~ Normal(mean, std)[cell] drawn per lookup",
-                                   "value": n3 / el3, "unit": "solves/s", "us_per_solve": el3 / n3 * 1e6,
-                                   "draws_per_solve": K3 * (2 * T + 1) + T,
-                                   "roofline": {"bound": "hbm", "achieved": bytes3 / (r3 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": bytes3 / (r3 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic3,
-                                                "kernel": "bn::rollout_sampled_kernel (one launch per solve: rollouts, ticket merge, previous tail)",
-                                                "kernel_ms": r3, "algorithmic_bytes_per_launch": bytes3}}
-        # ---- BASELINE configs[4] on one GPU: 512x512 map, K=16384, T=100 (LDS-tiled 43x43 window) ----
-        if world == 1:
-            K5, T5, G5 = 16384, 100, 512
-            inst5 = synth.make_instance(G5, seed=0, resolution=RES)
-            pl5 = NativeMPPI(horizon=T5, num_samples=K5, grid_size=G5, resolution=RES, device_id=local, profile=True,
-                             stream=torch.cuda.current_stream().cuda_stream)
-            pl5.set_map(inst5.risk.numpy()); pl5.set_goal(inst5.goal.numpy())
-            st5 = inst5.start.cuda()
-            n5 = max(50, a.steps // 20)
-            timed_solves(pl5, st5, None, kind, 30, torch.cuda.synchronize)
-            pl5.kernel_ms()
-            el5 = timed_solves(pl5, st5, None, kind, n5, torch.cuda.synchronize)
-            r5, f5, _ = pl5.kernel_ms()
-            bytes5 = pl5.algorithmic_bytes(injected_noise=False)
-            pl5.close()
-            traffic5 = None
-            if os.path.exists(tpath):
-                try:
-                    traffic5 = json.load(open(tpath)).get(f"rollout_K{K5}_T{T5}_G{G5}")
-                except Exception:
-                    traffic5 = None
-            out["config5_one_gpu"] = {"workload": f"BASELINE configs[4] on one GPU: mppi_solve K={K5} T={T5} map={G5}x{G5}",
-                                      "value": n5 / el5, "unit": "solves/s", "us_per_solve": el5 / n5 * 1e6,
-                                      "roofline": {"bound": "hbm", "achieved": bytes5 / (r5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": bytes5 / (r5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic5,
-                                                   "kernel_ms": r5, "finish_kernel_ms": f5, "algorithmic_bytes_per_launch": bytes5}}
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -23,6 +23,7 @@ BN_FLAG_NO_PIPELINE = 32
 BN_FLAG_SAMPLED_SLIP = 64
 BN_FLAG_WAVE_KERNEL = 128
 BN_FLAG_ROLE_KERNEL = 256
+BN_FLAG_LEAN = 512
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
 ABI_VERSION = 1
 
@@ -75,6 +76,7 @@ SYMBOLS = {
     "bn_mppi_get_controls": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_get_philox_noise": (C.c_int, [_H, C.c_int32, C.c_uint64, _FP]),
     "bn_mppi_get_top_samples": (C.c_int, [_H, C.c_int32, C.c_int32, _FP, _FP]),
+    "bn_mppi_reroll_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "bn_mppi_device_buffer": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bn_mppi_solve_count": (C.c_uint64, [_H]),
     "bn_mppi_row_pitch": (C.c_int32, [_H]),

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -67,12 +68,16 @@ struct bn_mppi {
     float *d_X = nullptr, *d_U = nullptr, *d_w = nullptr, *d_cost_out = nullptr;
     float *d_cost[2] = {nullptr, nullptr}, *d_part[2] = {nullptr, nullptr}, *d_state_copy[2] = {nullptr, nullptr};
     float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
+    float *d_mean_used = nullptr;    // the mean the latest finished solve sampled around (re-rolls)
     int *d_idx = nullptr;
+    const float *last_eps = nullptr; // noise of the latest solve (caller-owned unless BN_NOISE_HOST_KT2) and its layout
+    bn::EpsMode last_mode = bn::kEpsPhilox;
     float *d_slip_std = nullptr;     // sampled-slip mode
     float *d_ustar2[2] = {nullptr, nullptr}, *d_stats2[2] = {nullptr, nullptr};   // ticket-merge outputs by solve parity
     std::vector<float> dwa_stage;    // host staging of bn_mppi_dwa_solve's upload
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
+    size_t resident_wgs = 1024;      // role-kernel workgroups the device holds at once (LDS- and wave-limited) x CUs
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
     bool ticket_mode = false;        // one launch per solve: ticket merge by the last workgroup + the previous tail as aux
@@ -97,7 +102,24 @@ struct bn_mppi {
 
 namespace {
 
-int bind_device(const bn_mppi *h) { return hipSetDevice(h->cfg.device_id) == hipSuccess ? BN_OK : BN_ERR_HIP; }
+// Every entry point works on the handle's device and leaves the calling thread's current device as it found it
+// (one process may drive several GPUs; torch tracks its own notion of the current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false, ok = true;
+    explicit DeviceGuard(int want)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != want) {
+            ok = hipSetDevice(want) == hipSuccess;
+            changed = ok;
+        }
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define BN_BIND(h) DeviceGuard bn_guard_((h)->cfg.device_id); if (!bn_guard_.ok) return fail(BN_ERR_HIP, "hipSetDevice failed")
 
 size_t buffer_bytes(const bn_mppi *h, bn_buffer_id id)
 {
@@ -192,7 +214,9 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
                     sizeof(bn_mppi_config));
     if (cfg->horizon < 1 || cfg->num_samples < 1 || cfg->num_instances < 1 || cfg->grid_size < 1)
         return fail(BN_ERR_INVALID, "horizon, num_samples, num_instances and grid_size must be >= 1");
-    if (cfg->num_instances > 65535) return fail(BN_ERR_INVALID, "num_instances must be <= 65535");
+    if (cfg->num_instances > 32768) return fail(BN_ERR_INVALID, "num_instances must be <= 32768");
+    if ((cfg->flags & BN_FLAG_LEAN) && (cfg->flags & BN_FLAG_SAMPLED_SLIP))
+        return fail(BN_ERR_INVALID, "BN_FLAG_LEAN is not available in sampled-slip mode");
     if (!(cfg->resolution > 0.0f) || !(cfg->lambda_ > 0.0f) || !(cfg->dt > 0.0f))
         return fail(BN_ERR_INVALID, "resolution, lambda_ and dt must be positive");
     for (int d = 0; d < 2; ++d)
@@ -214,7 +238,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         return fail(BN_ERR_NO_DEVICE, "no HIP device visible: the MPPI planner has no CPU fallback");
     if (cfg->device_id < 0 || cfg->device_id >= ndev)
         return fail(BN_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
-    BN_HIP(hipSetDevice(cfg->device_id));
+    DeviceGuard guard(cfg->device_id);
+    if (!guard.ok) return fail(BN_ERR_HIP, "hipSetDevice(%d) failed", cfg->device_id);
     hipDeviceProp_t prop;
     BN_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -238,6 +263,14 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.umin1 = cfg->u_min[1]; p.umax1 = cfg->u_max[1];
     p.seed = cfg->seed;
     p.store_u = (cfg->flags & BN_FLAG_STORE_CONTROLS) ? 1 : 0;
+    p.lean = (cfg->flags & BN_FLAG_LEAN) ? 1 : 0;
+    // Workgroup i of a launch runs on XCD i % 8 (observed, used for speed only).  xs = 3 interleaves 8 instances along grid x
+    // so that the workgroups of one instance share an XCD's L2 (rollout_grid); measured SLOWER (64 instances: 29.2 vs 28.1 us,
+    // 60: 28.5 vs 24.9): the dispatcher then fills the CUs unevenly (3 to 5 workgroups per CU instead of 4, tools/block_trace.py)
+    // and a few workgroups wait for a second round.  Default: instance per grid row, workgroups of an instance spread over the XCDs.
+    p.xs = 0;
+    if (const char *e = std::getenv("BN_XCD_PACK")) p.xs = (e[0] == '1') ? 3 : 0;      // experiments (tools/r2_measure.py)
+
     h->n_maps = (cfg->flags & BN_FLAG_SHARED_MAP) ? 1 : p.B;
     p.map_stride = (h->n_maps == 1) ? 0 : p.G * p.G;
 
@@ -254,6 +287,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
                     bn::rollout_lds_bytes(p));
     }
 
+    {
+        const size_t by_lds = lds_budget / std::max<size_t>(bn::rollout_lds_bytes(p), 1);
+        const size_t by_waves = 32 / (bn::kRolloutThreads / 64);
+        h->resident_wgs = std::max<size_t>(1, std::min(by_lds, by_waves)) * (size_t)std::max(prop.multiProcessorCount, 1);
+    }
     int rc = BN_OK;
     auto alloc = [&](auto **ptr, size_t bytes) {
         if (rc != BN_OK) return;
@@ -266,7 +304,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     alloc(&h->d_state, B * 3 * 4);
     alloc(&h->d_goal, B * 2 * 4);
     alloc(&h->d_mean, B * T * 2 * 4);
-    alloc(&h->d_X, B * (T + 1) * 3 * (size_t)p.Kp * 4);
+    if (!p.lean) alloc(&h->d_X, B * (T + 1) * 3 * (size_t)p.Kp * 4);      // lean mode never materialises _state_seq_batch
+    alloc(&h->d_mean_used, B * T * 2 * 4);
     // the throughput kernel keeps its controls in this buffer instead of an LDS tile, requested or not
     const bool want_wave = !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_ROLE_KERNEL | BN_FLAG_SAMPLED_SLIP)) && p.nblk <= 32 &&
                            ((cfg->flags & BN_FLAG_WAVE_KERNEL) || (size_t)p.B * (p.nblk + 1) > kWaveKernelMinWorkgroups);
@@ -299,38 +338,40 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.map = h->d_map; p.state = h->d_state; p.goal = h->d_goal; p.mean = h->d_mean; p.eps = nullptr;
     p.X = h->d_X; p.U = h->d_U; p.cost = h->d_cost[0]; p.part = h->d_part[0]; p.w = h->d_w;
     p.state_copy = h->d_state_copy[0]; p.cost_out = h->d_cost_out;
-    p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats;
+    p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats; p.mean_used = h->d_mean_used;
     // every rollout workgroup re-merges the previous solve's nblk partials: only worth it while they are few
     p.slip_on = (cfg->flags & BN_FLAG_SAMPLED_SLIP) ? 1 : 0;
     h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 32 && !p.slip_on;
     // throughput kernel: launches with more workgroups than the role kernel keeps resident in one round (4 per CU)
     h->wave_kernel = h->pipelined && want_wave;
+    // (late allocations also go through `alloc`: a failure anywhere destroys the handle and everything it owns)
     if (p.slip_on) {
-        BN_HIP(hipMalloc((void **)&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4));
-        BN_HIP(hipMemset(h->d_slip_std, 0, (size_t)h->n_maps * p.G * p.G * 4));
+        alloc(&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4);
         p.slip_std = h->d_slip_std;
         for (int q = 0; q < 2; ++q) {
-            BN_HIP(hipMalloc((void **)&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4));
-            BN_HIP(hipMalloc((void **)&h->d_stats2[q], (size_t)p.B * 2 * 4));
+            alloc(&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4);
+            alloc(&h->d_stats2[q], (size_t)p.B * 2 * 4);
         }
-        BN_HIP(hipMalloc((void **)&h->d_ticket, (size_t)p.B * 65 * 4));
-        BN_HIP(hipMemset(h->d_ticket, 0, (size_t)p.B * 65 * 4));
-        BN_HIP(hipMalloc((void **)&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4));
+        alloc(&h->d_ticket, (size_t)p.B * 65 * 4);
+        alloc(&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4);
         p.ticket = h->d_ticket; p.gpart = h->d_gpart;
         h->ticket_mode = !(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p);
     } else if (!h->pipelined && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 1024 && bn::finish_lds_bytes(p) + 256 <= bn::rollout_lds_bytes(p)) {
         // K > 2048: too many partials for every workgroup to re-merge; the last workgroup of a launch merges them
         for (int q = 0; q < 2; ++q) {
-            BN_HIP(hipMalloc((void **)&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4));
-            BN_HIP(hipMalloc((void **)&h->d_stats2[q], (size_t)p.B * 2 * 4));
+            alloc(&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4);
+            alloc(&h->d_stats2[q], (size_t)p.B * 2 * 4);
         }
-        BN_HIP(hipMalloc((void **)&h->d_ticket, (size_t)p.B * 65 * 4));
-        BN_HIP(hipMemset(h->d_ticket, 0, (size_t)p.B * 65 * 4));
-        BN_HIP(hipMalloc((void **)&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4));
+        alloc(&h->d_ticket, (size_t)p.B * 65 * 4);
+        alloc(&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4);
         p.gpart = h->d_gpart;
         h->ticket_mode = true;             // p.ticket stays null in h->p: only the one-launch path selects the ticket kernel
     }
-    BN_HIP(hipDeviceSynchronize());
+    if (rc == BN_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(BN_ERR_HIP, "hipDeviceSynchronize failed after allocation");
+    if (rc != BN_OK) {
+        bn_mppi_destroy(h);
+        return rc;
+    }
     *out = h;
     return BN_OK;
 }
@@ -338,14 +379,14 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
 void bn_mppi_destroy(bn_mppi_t *h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device_id);
+    DeviceGuard guard(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1],
                     h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
                     h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
-                    h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket, h->d_gpart};
+                    h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket, h->d_gpart, h->d_mean_used};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -357,7 +398,7 @@ int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_ki
 {
     if (int rc = check_instance(h, instance, true)) return rc;
     if (!risk) return fail(BN_ERR_INVALID, "risk is null");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     const size_t bytes = (size_t)h->p.G * h->p.G * 4;
     const hipMemcpyKind kind = where == BN_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const int lo = instance < 0 ? 0 : std::min(instance, h->n_maps - 1);
@@ -374,7 +415,7 @@ int bn_mppi_set_slip_std(bn_mppi_t *h, int32_t instance, const float *stdv, bn_m
     if (int rc = check_instance(h, instance, true)) return rc;
     if (!stdv) return fail(BN_ERR_INVALID, "std is null");
     if (!h->p.slip_on) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_SAMPLED_SLIP");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t bytes = (size_t)h->p.G * h->p.G * 4;
@@ -399,7 +440,7 @@ int bn_mppi_set_goal(bn_mppi_t *h, int32_t instance, const float goal_host[2])
 {
     if (int rc = check_instance(h, instance, true)) return rc;
     if (!goal_host) return fail(BN_ERR_INVALID, "goal is null");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const int lo = instance < 0 ? 0 : instance, hi = instance < 0 ? h->p.B : instance + 1;
@@ -411,7 +452,7 @@ int bn_mppi_set_goal(bn_mppi_t *h, int32_t instance, const float goal_host[2])
 int bn_mppi_set_mean(bn_mppi_t *h, int32_t instance, const float *mean_host)
 {
     if (int rc = check_instance(h, instance, true)) return rc;
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;           // afterwards the mean buffer is authoritative again
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->p.T * 2;
@@ -427,7 +468,7 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
 {
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!mean_host) return fail(BN_ERR_INVALID, "null output");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->p.T * 2;
@@ -444,7 +485,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     if (!h->map_set || !h->goal_set) return fail(BN_ERR_STATE, "set_map and set_goal must precede solve");
     if ((noise == BN_NOISE_PHILOX) != (eps == nullptr))
         return fail(BN_ERR_INVALID, "eps must be NULL exactly when noise == BN_NOISE_PHILOX");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
 
     bn::SolveParams p = h->p;
     const size_t B = p.B, K = p.K, T = p.T;
@@ -511,6 +552,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         h->ev_used += 3;
         BN_HIP(hipEventRecord(ev[0], h->stream));
     }
+    h->last_eps = p.eps;
+    h->last_mode = mode;
     const int cur = (int)(h->solves & 1), prev = cur ^ 1;
     p.solve = h->solves;
     p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state_copy = h->d_state_copy[cur];
@@ -528,6 +571,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             h->ep_len += 1;
         }
         p.wave_kernel = (h->wave_kernel && !h->in_episode) ? 1 : 0;
+        // more workgroups than the role kernel keeps resident at once (4 per CU x 256 CUs): the aux workgroups run in freed slots
+        p.aux_prio = (!p.wave_kernel && (size_t)p.B * (p.nblk + 1) > h->resident_wgs) ? 1 : 0;
         if (!p.wave_kernel && !p.store_u) p.U = nullptr;          // the buffer exists for the throughput kernel only
         BN_HIP(bn::launch_rollout(p, mode, h->stream));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
@@ -584,6 +629,7 @@ int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (first_rollout < 0 || first_rollout + h->p.K > 0x7fffffffLL) return fail(BN_ERR_INVALID, "first_rollout out of range");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     h->p.k0 = (int)first_rollout;
     return BN_OK;
@@ -613,7 +659,7 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->shard_pending) return fail(BN_ERR_STATE, "no sharded solve in flight");
     if (!all_partials_device || total_workgroups < h->p.nblk) return fail(BN_ERR_INVALID, "need the partials of every shard");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     bn::SolveParams p = h->p;
     const int cur = (int)((h->solves - 1) & 1);
     p.solve = p.tail_solve = h->solves - 1;
@@ -642,7 +688,7 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
 {
     if (!h || !latent_mean || !latent_std) return fail(BN_ERR_INVALID, "null argument");
     if (!(goal_threshold >= 0.0f) || !(delta_t > 0.0f)) return fail(BN_ERR_INVALID, "goal_threshold >= 0 and delta_t > 0 required");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t bytes = (size_t)h->n_maps * h->p.G * h->p.G * 4;
@@ -666,7 +712,7 @@ int bn_mppi_env_step(bn_mppi_t *h, const float *actions_device, float *states_de
 {
     if (!h || !actions_device || !states_device || !rewards_device || !terminated_device) return fail(BN_ERR_INVALID, "null argument");
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_step");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     BN_HIP(bn::launch_env_step(h->p, actions_device, states_device, rewards_device, terminated_device, z_device, step_index, h->stream));
     return BN_OK;
 }
@@ -677,7 +723,7 @@ int bn_mppi_env_collision_check(bn_mppi_t *h, const float *states_device, int32_
     if (!h || !states_device || !out_device) return fail(BN_ERR_INVALID, "null argument");
     if (n_positions < 1) return fail(BN_ERR_INVALID, "n_positions must be >= 1");
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_collision_check");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     BN_HIP(bn::launch_env_collision(h->p, states_device, n_positions, stuck_threshold, z_device, draw_index, out_device, h->stream));
     return BN_OK;
 }
@@ -689,7 +735,7 @@ int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, b
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_episode_async");
     if (!h->pipelined) return fail(BN_ERR_INVALID, "the device-side closed loop needs the pipelined mode (num_samples <= 2048)");
     if (n_steps < 1) return fail(BN_ERR_INVALID, "n_steps must be >= 1");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;            // anything pending belongs to the pre-episode state
     const size_t B = h->p.B;
     if (n_steps > h->ep_steps) {
@@ -725,7 +771,7 @@ int bn_mppi_episode_log(bn_mppi_t *h, float *states_host, float *rewards_host, f
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->d_ep_states || h->ep_len < 1) return fail(BN_ERR_STATE, "no episode has been run");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t B = h->p.B, n = (size_t)h->ep_len;
     if (states_host) BN_HIP(hipMemcpy(states_host, h->d_ep_states, (n + 1) * B * 3 * 4, hipMemcpyDeviceToHost));
@@ -742,7 +788,7 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
     if (!h || !states_host || !actions_host) return fail(BN_ERR_INVALID, "null argument");
     if (num_actions < 1 || num_actions > 1024) return fail(BN_ERR_INVALID, "num_actions must be in [1, 1024]");
     if (!h->map_set || !h->goal_set) return fail(BN_ERR_STATE, "set_map and set_goal must precede dwa_solve");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     const size_t B = h->p.B, NA = num_actions, T1 = h->p.T + 1;
     // scratch layout: actions | stage goal | X | cost | w | best | best states | states
@@ -796,7 +842,7 @@ int bn_mppi_dwa_buffers(bn_mppi_t *h, int32_t num_actions, const float **states_
 int bn_mppi_sync(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     return BN_OK;
@@ -805,7 +851,7 @@ int bn_mppi_sync(bn_mppi_t *h)
 int bn_mppi_flush(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     return flush_tail(h);
 }
 
@@ -822,11 +868,38 @@ int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, c
     return BN_OK;
 }
 
+// Rows of the latest solve's trajectory batch, regenerated (launch_reroll).  The tail of that solve must have run
+// (mean_used, state copy); the caller's eps block of that solve must still be alive when the noise was injected.
+static int reroll_rows(bn_mppi_t *h, int32_t instance, const int *idx_device, int32_t n, float *out_device)
+{
+    if (h->p.slip_on) return fail(BN_ERR_INVALID, "re-rolling is not available in sampled-slip mode");
+    if (h->solves == 0) return fail(BN_ERR_STATE, "no solve has run");
+    if (h->shard_pending) return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
+    if (int rc = flush_tail(h)) return rc;
+    bn::SolveParams p = h->p;
+    const int cur = (int)((h->solves - 1) & 1);
+    p.solve = h->solves - 1;
+    p.state = h->d_state_copy[cur];
+    p.eps = h->last_eps;
+    BN_HIP(bn::launch_reroll(p, h->last_mode, instance, idx_device, n, out_device, h->stream));
+    return BN_OK;
+}
+
+int bn_mppi_reroll_async(bn_mppi_t *h, int32_t instance, const int32_t *idx_device, int32_t n, float *out_device)
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (n < 0 || (!idx_device && n > h->p.K)) return fail(BN_ERR_INVALID, "n=%d out of range", n);
+    if (n == 0) return BN_OK;
+    if (!out_device) return fail(BN_ERR_INVALID, "null output");
+    BN_BIND(h);
+    return reroll_rows(h, instance, idx_device, n, out_device);
+}
+
 static int copy_out(bn_mppi_t *h, int32_t instance, const float *dev, size_t per_instance, float *out_host)
 {
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     BN_HIP(hipMemcpy(out_host, dev + (size_t)instance * per_instance, per_instance * 4, hipMemcpyDeviceToHost));
@@ -847,9 +920,12 @@ int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host)
 {
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     const size_t K = h->p.K, Kp = h->p.Kp, T1 = h->p.T + 1, n = K * T1 * 3;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
+    if (h->p.lean) {                                   // not materialised: regenerate all K rows
+        if (int rc = reroll_rows(h, instance, nullptr, (int32_t)K, h->d_scratch)) return rc;
+    } else
     BN_HIP(bn::launch_states_to_reference(h->d_X + (size_t)instance * Kp * T1 * 3, h->d_scratch, (int)K, (int)Kp, (int)T1,
                                           h->stream));
     BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -862,7 +938,7 @@ int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host)
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     if (!h->d_U || !h->p.store_u) return fail(BN_ERR_STATE, "controls are only stored with BN_FLAG_STORE_CONTROLS");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     const size_t K = h->p.K, Kp = h->p.Kp, T = h->p.T, n = K * T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
     BN_HIP(bn::launch_controls_to_reference(h->d_U + (size_t)instance * Kp * T * 2, h->d_scratch, (int)K, (int)Kp, (int)T,
@@ -876,7 +952,7 @@ int bn_mppi_get_philox_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_inde
 {
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     const size_t n = (size_t)h->p.K * h->p.T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
     BN_HIP(bn::launch_philox_noise(h->d_scratch, h->p.seed, solve_index, instance, h->p.K, h->p.T, h->p.k0, h->stream));
@@ -890,7 +966,7 @@ int bn_mppi_get_slip_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_index,
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!zt_host || !zc_host || !zo_host) return fail(BN_ERR_INVALID, "null output");
     if (!h->p.slip_on) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_SAMPLED_SLIP");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     const size_t K = h->p.K, T = h->p.T, nt = K * T, nc = K * (T + 1);
     if (int rc = ensure_scratch(h, (nt + nc + T) * 4)) return rc;
     float *zt = h->d_scratch, *zc = zt + nt, *zo = zc + nc;
@@ -908,7 +984,7 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
     if (n < 0 || n > h->p.K) return fail(BN_ERR_INVALID, "n=%d must satisfy 0 <= n <= K=%d", n, h->p.K);  // mppi.py:229
     if (n == 0) return BN_OK;
     if (!states_host || !weights_host) return fail(BN_ERR_INVALID, "null output");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     const size_t K = h->p.K, T1 = h->p.T + 1;
     std::vector<float> w(K);
     if (int rc = flush_tail(h)) return rc;
@@ -927,6 +1003,9 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
     }
     if (int rc = ensure_scratch(h, (size_t)n * T1 * 3 * 4)) return rc;
     BN_HIP(hipMemcpyAsync(h->d_idx, idx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (h->p.lean) {                                   // the n winners are re-rolled, bit-identical to a stored batch
+        if (int rc = reroll_rows(h, instance, h->d_idx, n, h->d_scratch)) return rc;
+    } else
     BN_HIP(bn::launch_gather_states(h->d_X + (size_t)instance * h->p.Kp * T1 * 3, h->d_idx, h->d_scratch, n, h->p.Kp,
                                     (int)T1, h->stream));
     BN_HIP(hipMemcpyAsync(states_host, h->d_scratch, (size_t)n * T1 * 3 * 4, hipMemcpyDeviceToHost, h->stream));
@@ -954,7 +1033,7 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!(h->cfg.flags & BN_FLAG_PROFILE)) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_PROFILE");
-    if (bind_device(h)) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    BN_BIND(h);
     if (h->pipelined || h->ticket_mode) {
         // close the open group with one more event *before* the flush, then average complete groups only
         const int open = h->prof_in_group;
@@ -1008,7 +1087,7 @@ int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise)
     const int64_t K = h->p.K, T = h->p.T, G = h->p.G;
     int64_t bytes = 4 * G * G            // risk map read once
                     + (8 * T + 12)       // mean, state
-                    + 12 * K * (T + 1)   // _state_seq_batch write
+                    + (h->p.lean ? 0 : 12 * K * (T + 1))   // _state_seq_batch write (not in lean mode)
                     + 4 * K              // weights write
                     + 8 * T + 12 * (T + 1);   // U*, X* write
     if (noise != BN_NOISE_PHILOX) bytes += 8 * K * T;   // injected noise read

@@ -25,7 +25,7 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 #ifdef BN_TIMING
 #define BN_STAMP(slot)                                                                                   \
     do {                                                                                                 \
-        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                          \
+        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)   /* instance 0, workgroup 0 */ \
             p.stamps[slot] = __builtin_readcyclecounter();                                               \
     } while (0)
 #define BN_STAMP_ANY(slot)                                                                               \
@@ -56,6 +56,28 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 enum Geo : int { kGeoGeneral = 0, kGeoPow2 = 1, kGeoPow2Origin0 = 2 };
 
 struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; };   // window origin (cells), as floats, edge, edge-1
+
+// Which workgroup of which instance this is (see rollout_grid): rollout workgroup `blk` of instance `b`, or the aux
+// workgroup of instance `b` (tail of the previous solve).  Rows past the instances hold the aux workgroups, so they are
+// dispatched last; with xs = 3 the workgroups of one instance share an XCD (and its L2: window rows, partials).
+struct WgId { int b, blk; bool aux, idle; };
+
+__device__ __forceinline__ WgId decode_wg(const SolveParams &p)
+{
+    const int rows = (p.B + (1 << p.xs) - 1) >> p.xs;
+    WgId r;
+    if ((int)blockIdx.y >= rows) {
+        r.aux = true;
+        r.blk = p.nblk;
+        r.b = ((int)blockIdx.y - rows) * (int)gridDim.x + (int)blockIdx.x;
+    } else {
+        r.aux = false;
+        r.blk = (int)blockIdx.x >> p.xs;
+        r.b = ((int)blockIdx.y << p.xs) + ((int)blockIdx.x & ((1 << p.xs) - 1));
+    }
+    r.idle = r.b >= p.B;
+    return r;
+}
 
 template <int GEO>
 __device__ __forceinline__ int raw_cell(float v, float origin, float res, float inv_res)
@@ -459,6 +481,10 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     const float sx = state_all[b * 3 + 0], sy = state_all[b * 3 + 1], sth = state_all[b * 3 + 2];
     BN_STAMP(8);
 
+    // the merge's loads go out before the window staging (which waits for the state): one memory round trip for both
+    MergeLoads pre;
+    const bool pre_ok = !p.tail_merged && nblk <= 64;
+    if (pre_ok) pre = merge_issue(part, nblk, T, tid);
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN && !p.slip_on) {
         w = window_origin<GEO>(p, sx, sy);
@@ -477,9 +503,10 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         S = p.stats_prev[b * 2 + 1];
         __syncthreads();
     } else {
-        merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, nullptr);
+        merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, pre_ok ? &pre : nullptr);
         for (int j = tid; j < 2 * T; j += NT) {
             p.ustar[(size_t)b * 2 * T + j] = us[j];
+            if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = p.mean[(size_t)b * 2 * T + j];   // what this solve sampled around
             p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
         }
     }
@@ -634,7 +661,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
 constexpr int kTicketStride = 1 + 64;
 
 template <int NT>
-__device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, float *scratch)
+__device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, int blk, float *scratch)
 {
     const int T = p.T, tid = threadIdx.x, PS = 2 + 2 * p.T;
     float *us = scratch, *sc = us + 2 * T, *red = sc + p.nblk;
@@ -644,7 +671,7 @@ __device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, float 
     const float *rows = part;
     int nrows = p.nblk;
     if (p.nblk > 64) {
-        const int g = blockIdx.x / kGroupRows, ng = (p.nblk + kGroupRows - 1) / kGroupRows;
+        const int g = blk / kGroupRows, ng = (p.nblk + kGroupRows - 1) / kGroupRows;
         const int in_group = min(kGroupRows, p.nblk - g * kGroupRows);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -668,6 +695,7 @@ __device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, float 
     merge_partials<NT, true, false>(rows, nrows, T, us, sc, red, tid, m, S, nullptr);
     for (int j = tid; j < 2 * T; j += NT) {
         p.ustar_cur[(size_t)b * 2 * T + j] = us[j];
+        if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = p.mean[(size_t)b * 2 * T + j];   // what this solve sampled around
         p.mean[(size_t)b * 2 * T + j] = us[j];         // _previous_action_seq = U*, no shift (mppi.py:217)
     }
     if (tid == 0) { p.stats_cur[b * 2 + 0] = m; p.stats_cur[b * 2 + 1] = S; }

@@ -27,6 +27,11 @@ struct SolveParams {
     int store_u;
     int wave_kernel;     // launch the one-wave-per-64-rollouts throughput variant (many workgroups per launch)
     int k0;              // global index of this handle's rollout 0 (K-sharded solve: rank r owns rollouts [k0, k0 + K)); keys the Philox stream
+    int xs;              // log2 of the instances interleaved along grid x (rollout_grid / decode_wg): 3 keeps the workgroups of
+                         // one instance on one XCD (workgroup i runs on XCD i % 8), 0 is instance-per-row
+    int aux_prio;        // the aux workgroups run at wave priority 3: set when the launch exceeds one resident round, so that they
+                         // start late (in slots freed by the first rollout workgroups) and must not finish last
+    int lean;            // lean mode: the (K,T+1,3) trajectory batch is not materialised (bn_mppi_reroll regenerates rows on demand)
     float res, inv_res;
     float x0, y0;        // index origin == lower clamp (reference grid_map.py:199-201, robot_model.py:93-94)
     float x_hi, y_hi;    // upper clamp
@@ -41,6 +46,7 @@ struct SolveParams {
     const float *state;  // (B, 3)
     const float *goal;   // (B, 2)
     float *mean;         // (B, T, 2)   read by rollout, rewritten by finish
+    float *mean_used;    // (B, T, 2)   lean mode: the mean the latest finished solve sampled around (kept for re-rolls)
     const float *eps;    // per EpsMode, or nullptr
     float *X;            // (B, T+1, 3, Kp)
     float *U;            // (B, T, 2, Kp) or nullptr
@@ -83,6 +89,18 @@ struct SolveParams {
     unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0
 };
 
+// Launch grid of the rollout kernels.  x = workgroup-of-instance index interleaved with 2^xs instances, y = groups of
+// 2^xs instances, then -- LAST in dispatch order -- the rows holding the B aux workgroups (tail of the previous solve):
+// they start in the slots the first rollout workgroups free, instead of pushing the last instances' rollouts into a second
+// residency round (64 x 16 rollout workgroups of K=1024 fill the chip's 4 x 256 slots exactly).
+inline dim3 rollout_grid(const SolveParams &p, bool aux)
+{
+    const unsigned gx = (unsigned)p.nblk << p.xs;
+    const unsigned rows = ((unsigned)p.B + (1u << p.xs) - 1) >> p.xs;
+    const unsigned aux_rows = aux ? ((unsigned)p.B + gx - 1) / gx : 0;
+    return dim3(gx, rows + aux_rows);
+}
+
 size_t rollout_lds_bytes(const SolveParams &p);
 size_t finish_lds_bytes(const SolveParams &p);
 size_t wave_lds_bytes(const SolveParams &p);
@@ -90,6 +108,8 @@ int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
+// rows idx[0..n) (nullptr: 0..n) of instance b's trajectory batch of the solve described by p (p.solve, p.eps, p.state, p.mean_used)
+hipError_t launch_reroll(const SolveParams &p, EpsMode mode, int b, const int *idx, int n, float *out_n_T1_3, hipStream_t s);
 hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s);
 bool sampled_fused(const SolveParams &p);   // the sampled launch merges by ticket and carries the previous tail (LDS-window variant)
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,

@@ -37,6 +37,56 @@ __global__ __launch_bounds__(NT) void finish_kernel(const SolveParams p)
 }
 
 // ------------------------------------------------------------------------------
+// Re-roll: rows of _state_seq_batch (mppi.py:119-125, 160-165) of the LATEST solve regenerated on demand -- the same noise
+// (Philox stream position or the caller's eps), the mean that solve sampled around (mean_used), the state it started from,
+// the same device functions in the same order as the rollout kernels: bit-identical to what a full-API solve stored.
+// This is what lets lean mode (BN_FLAG_LEAN) skip the 12*K*(T+1)-byte trajectory dump and still serve get_top_samples.
+// grid = ceil(n / 256) workgroups of instance b, block = 256; thread i rolls rollout idx[i] (idx == nullptr: rollout i).
+// out (n, T+1, 3) in the reference's layout.  LDS: [ window ].
+// ------------------------------------------------------------------------------
+template <int EPS, int GEO, bool LDSWIN>
+__global__ __launch_bounds__(256) void reroll_kernel(const SolveParams p, int b, const int *__restrict__ idx, int n,
+                                                      float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.T, tid = threadIdx.x;
+    float *win = smem;
+    const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
+    const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+    const float *ml = p.mean_used + (size_t)b * 2 * T;
+    Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (LDSWIN) {
+        w = window_origin<GEO>(p, sx, sy);
+        stage_window(win, map, w, p.WN, p.G, tid, 256);
+    }
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const int k = idx ? idx[i] : i;
+        float *Xo = out + (size_t)i * (T + 1) * 3;
+        Chain c;
+        c.x = sx; c.y = sy; c.th = sth;                   // mppi.py:160
+        sincos_spec(c.th, c.sn, c.cs);
+        c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
+        for (int t = 0; t < T; t += 2) {
+            float e[4], xn, yn, tn;
+            noise_pair<EPS>(p, b, k, t, e);
+            const float u0 = clampf(ml[2 * t] + p.sigma0 * e[0], p.umin0, p.umax0);          // mppi.py:152-157
+            const float u1 = clampf(ml[2 * t + 1] + p.sigma1 * e[1], p.umin1, p.umax1);
+            if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+            else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, u0, u1, xn, yn, tn);
+            Xo[3 * t] = xn; Xo[3 * t + 1] = yn; Xo[3 * t + 2] = tn;
+            if (t + 1 < T) {
+                const float v0 = clampf(ml[2 * t + 2] + p.sigma0 * e[2], p.umin0, p.umax0);
+                const float v1 = clampf(ml[2 * t + 3] + p.sigma1 * e[3], p.umin1, p.umax1);
+                chain_step<GEO, LDSWIN, false>(p, win, map, w, c, v0, v1, xn, yn, tn);
+                Xo[3 * t + 3] = xn; Xo[3 * t + 4] = yn; Xo[3 * t + 5] = tn;
+            }
+        }
+        Xo[3 * T] = c.x; Xo[3 * T + 1] = c.y; Xo[3 * T + 2] = c.th;
+    }
+}
+
+// ------------------------------------------------------------------------------
 // DWA ("next" row N3): reference src/planners/local_planners/dwa.py:116-258.  NA constant-control candidates
 // (the dynamic window grid, built by the host exactly as dwa.py:168-199 does) are rolled out with the same
 // transit / aliasing as MPPI (dwa.py:224-227), costed with the stage cost against the sub-goal and the
@@ -273,6 +323,41 @@ hipError_t launch_finish(const SolveParams &p, hipStream_t s)
     case kGeoPow2Origin0: return win ? launch_finish_t<kGeoPow2Origin0, true>(p, s) : launch_finish_t<kGeoPow2Origin0, false>(p, s);
     case kGeoPow2: return win ? launch_finish_t<kGeoPow2, true>(p, s) : launch_finish_t<kGeoPow2, false>(p, s);
     default: return win ? launch_finish_t<kGeoGeneral, true>(p, s) : launch_finish_t<kGeoGeneral, false>(p, s);
+    }
+}
+
+namespace {
+template <int EPS, int GEO>
+hipError_t launch_reroll_g(const SolveParams &p, int b, const int *idx, int n, float *out, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * ((size_t)p.WN * p.WN + 4);
+    const dim3 grid((unsigned)std::min(256, (n + 255) / 256));
+    if (p.WN > 0) {
+        hipError_t e = ensure_lds(reroll_kernel<EPS, GEO, true>, lds);
+        if (e != hipSuccess) return e;
+        reroll_kernel<EPS, GEO, true><<<grid, dim3(256), lds, s>>>(p, b, idx, n, out);
+    } else {
+        reroll_kernel<EPS, GEO, false><<<grid, dim3(256), lds, s>>>(p, b, idx, n, out);
+    }
+    return hipGetLastError();
+}
+template <int EPS>
+hipError_t launch_reroll_e(const SolveParams &p, int b, const int *idx, int n, float *out, hipStream_t s)
+{
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: return launch_reroll_g<EPS, kGeoPow2Origin0>(p, b, idx, n, out, s);
+    case kGeoPow2: return launch_reroll_g<EPS, kGeoPow2>(p, b, idx, n, out, s);
+    default: return launch_reroll_g<EPS, kGeoGeneral>(p, b, idx, n, out, s);
+    }
+}
+}  // namespace
+
+hipError_t launch_reroll(const SolveParams &p, EpsMode mode, int b, const int *idx, int n, float *out, hipStream_t s)
+{
+    switch (mode) {
+    case kEpsPhilox: return launch_reroll_e<kEpsPhilox>(p, b, idx, n, out, s);
+    case kEpsKT2: return launch_reroll_e<kEpsKT2>(p, b, idx, n, out, s);
+    default: return launch_reroll_e<kEpsT2K>(p, b, idx, n, out, s);
     }
 }
 

@@ -142,7 +142,14 @@ int bn_risk_map_infer(int32_t device_id, void *stream, const float *mean, const 
         return fail(BN_ERR_INVALID, "confidence must be in [0, 1]");       // ModelConfig asserts the same (utils.py:27-33)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device visible: no CPU fallback");
-    if (hipSetDevice(device_id) != hipSuccess) return fail(BN_ERR_HIP, "hipSetDevice failed");
+    // work on `device_id`, leave the calling thread's current device as it was
+    struct Guard {
+        int prev = -1; bool changed = false, ok = true;
+        explicit Guard(int want) { if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+                                   if (prev != want) { ok = hipSetDevice(want) == hipSuccess; changed = ok; } }
+        ~Guard() { if (changed) (void)hipSetDevice(prev); }
+    } guard(device_id);
+    if (!guard.ok) return fail(BN_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = (hipStream_t)stream;
     const size_t cells = (size_t)grid_size * grid_size;
 #define RISK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { free_all(); return fail(BN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)

@@ -18,7 +18,7 @@ namespace {
 //   phase 4  wave 0    stage-cost sum (fp64, step order), rollout cost, softmin statistics; all: weighted control sums
 // The transit lookup of state t+1 and the stage-cost lookup of slot t hit the same cell (the un-clamped slot and
 // its clamped successor index alike, grid_map.py:209), so the chain hands its cell index on with the slot row.
-// grid = (ceil(K/64), B), block = 512, lane = rollout.
+// grid = rollout_grid, block = 512, lane = rollout.
 // LDS: [ slot rows (T+1) x 64 float4 | window WN^2 float2 | Zt TP x 64 | Zc TP x 64 | controls 2T x 65 | mean 2T |
 //        mean*inv_var 2T | e 64 | control cost 64 ],  TP = T+1 rounded up to even.
 // ------------------------------------------------------------------------------
@@ -41,14 +41,16 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
     float2 *win2 = reinterpret_cast<float2 *>(smem + 4 * 64 * (T + 1));
     float *Zt = reinterpret_cast<float *>(win2 + WN2), *Zc = Zt + 64 * TP;
     float *Ul = Zc + 64 * TP, *ml = Ul + 2 * T * kUPad, *mv = ml + 2 * T, *el = mv + 2 * T, *ad = el + 64;
-    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
-    if (blockIdx.x == p.nblk) {
+    const WgId wg = decode_wg(p);
+    if (wg.idle) return;
+    const int tid = threadIdx.x, lane = tid & 63, b = wg.b;
+    if (wg.aux) {
         // aux workgroup: weights, cost copy and X* of the previous solve (merged by its own last workgroup)
         finish_body<GEO, true, kSampledThreads>(p, b, nullptr, p.cost_prev, p.state_prev, smem);
         return;
     }
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k = blockIdx.x * 64 + lane;
+    const int k = wg.blk * 64 + lane;
     const bool active = k < K;
     const int kk = active ? k : K - 1;
     const float *__restrict__ mu = p.map + (size_t)b * p.map_stride;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         ml[j] = m;
         mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
     }
-    if (blockIdx.x == 0 && tid < 3) p.state_copy[b * 3 + tid] = p.state[b * 3 + tid];
+    if (wg.blk == 0 && tid < 3) p.state_copy[b * 3 + tid] = p.state[b * 3 + tid];
     __syncthreads();
 
     // ---- phase 1: controls and slip draws of every step ----
@@ -165,12 +167,12 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         const float esum = wave_sum(e);
         el[lane] = e;
         if (lane == 0) {
-            float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+            float *part = p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T);
             store_agent(part, zmax); store_agent(part + 1, esum);
         }
     }
     __syncthreads();
-    float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+    float *part = p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T);
     for (int j = tid; j < 2 * T; j += kSampledThreads) {
         const float *col = Ul + j * kUPad;
         float acc = 0.0f;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         store_agent(part + 2 + j, acc);
     }
     BN_STAMP(5);
-    if (p.ustar_cur) ticket_merge<kSampledThreads>(p, b, smem);   // one-launch mode; the slot rows are dead: their LDS is the merge scratch
+    if (p.ustar_cur) ticket_merge<kSampledThreads>(p, b, wg.blk, smem);   // one-launch mode; the slot rows are dead: their LDS is the merge scratch
 }
 
 // The same solve without the LDS window (BN_FLAG_NO_LDS_WINDOW, or a window/horizon too large for the LDS):
@@ -190,8 +192,10 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T, K = p.K;
     float *ml = smem, *mv = ml + 2 * T, *Ul = mv + 2 * T, *el = Ul + 2 * T * kUPad;
-    const int lane = threadIdx.x, b = blockIdx.y;
-    const int k = blockIdx.x * 64 + lane;
+    const WgId wg = decode_wg(p);
+    if (wg.idle) return;
+    const int lane = threadIdx.x, b = wg.b;
+    const int k = wg.blk * 64 + lane;
     const bool active = k < K;
     const int kk = active ? k : K - 1;
     const float *__restrict__ mu = p.map + (size_t)b * p.map_stride;
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         ml[j] = m;
         mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
     }
-    if (blockIdx.x == 0 && lane < 3) p.state_copy[b * 3 + lane] = p.state[b * 3 + lane];
+    if (wg.blk == 0 && lane < 3) p.state_copy[b * 3 + lane] = p.state[b * 3 + lane];
     __syncthreads();
     const size_t Kp = (size_t)p.Kp;
     float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
     const float esum = wave_sum(e);
     el[lane] = e;
     __syncthreads();
-    float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+    float *part = p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T);
     for (int j = lane; j < 2 * T; j += 64) {
         const float *col = Ul + j * kUPad;
         float acc = 0.0f;
@@ -309,7 +313,7 @@ template <int EPS, int GEO>
 hipError_t launch_sampled_g(const SolveParams &p, hipStream_t s)
 {
     const size_t lds_w = sizeof(float) * sampled_lds_floats(p.T, p.WN);
-    const dim3 grid(p.nblk + (sampled_fused(p) && p.have_prev ? 1 : 0), p.B);
+    const dim3 grid = rollout_grid(p, sampled_fused(p) && p.have_prev);
     if (sampled_fused(p)) {
 #define BN_SL(SU)                                                                                                      \
     do { hipError_t e = ensure_lds(rollout_sampled_kernel<EPS, GEO, SU>, lds_w); if (e != hipSuccess) return e;        \

@@ -16,14 +16,17 @@ namespace {
 // VALU-bound at ~7000 VALU instructions per workgroup against the role kernel's ~8700 + its skeleton (rocprofv3 SQ
 // counters, tools/pmc_sq.sh), and wins by 10-15 % from about 1500 workgroups per launch (96 instances of K=1024) on.
 // Same device functions in the same order per rollout: results are bit-identical to the role kernel.
-// grid = (ceil(K/64) [+1 aux], B), block = 64.  LDS: [ window | mean 2T | mean*inv_var 2T | e 64 | merge scratch ].
+// grid = rollout_grid, block = 64.  LDS: [ window | mean 2T | mean*inv_var 2T | e 64 | merge scratch ].
 // ------------------------------------------------------------------------------
 template <int EPS, int GEO, bool LDSWIN>
 __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (blockIdx.x == p.nblk) {
-        finish_body<GEO, LDSWIN, 64>(p, blockIdx.y, p.part_prev, p.cost_prev, p.state_prev, smem);
+    const WgId wg = decode_wg(p);
+    if (wg.idle) return;
+    if (wg.aux) {
+        if (p.aux_prio) __builtin_amdgcn_s_setprio(3);
+        finish_body<GEO, LDSWIN, 64>(p, wg.b, p.part_prev, p.cost_prev, p.state_prev, smem);
         return;
     }
     const int T = p.T, K = p.K;
@@ -32,8 +35,8 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     float *mv = ml + 2 * T;
     float *el = mv + 2 * T;
     float *sc = el + 64;                              // merge scratch: nblk scales + 32
-    const int lane = threadIdx.x, b = blockIdx.y;
-    const int k = blockIdx.x * kRolloutsPerBlock + lane;
+    const int lane = threadIdx.x, b = wg.b;
+    const int k = wg.blk * kRolloutsPerBlock + lane;
     const bool active = k < K;
     const int kk = active ? k : K - 1;
     const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
@@ -60,11 +63,12 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
             mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);      // mean[t] @ inv_cov (diagonal), mppi.py:179-180
         }
     }
-    if (blockIdx.x == 0 && lane == 0) {
+    if (wg.blk == 0 && lane == 0) {
         p.state_copy[b * 3 + 0] = sx; p.state_copy[b * 3 + 1] = sy; p.state_copy[b * 3 + 2] = sth;
     }
     __syncthreads();
     const size_t Kp = (size_t)p.Kp;
+    const bool lean = p.lean != 0;                    // lean mode: no trajectory batch (p.X is null)
     float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;
     float *Ub = p.U + (size_t)b * T * 2 * Kp + k;
 
@@ -79,8 +83,10 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     do {                                                                                                          \
         float xn, yn, tn;                                                                                         \
         chain_step<GEO, LDSWIN, FIRST>(p, win, map, w, c, (u0), (u1), xn, yn, tn);                                \
-        float *Xt = Xb + (size_t)(3 * (t)) * Kp;                                                                  \
-        Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                                 \
+        if (!lean) {                                                                                              \
+            float *Xt = Xb + (size_t)(3 * (t)) * Kp;                                                              \
+            Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                             \
+        }                                                                                                         \
         const float dx = xn - gx, dy = yn - gy;                                                                   \
         Sd += (double)(sqrt_cr(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));   /* objectives.py:47-53 */  \
         Ad += (double)(p.lambda_ * (mv[2 * (t)] * (u0) + mv[2 * (t) + 1] * (u1)));      /* mppi.py:178-182 */      \
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
         }
     }
 #undef BN_WAVE_STEP
-    {
+    if (!lean) {
         float *Xt = Xb + (size_t)(3 * T) * Kp;         // slot T: clamped / wrapped state
         Xt[0] = c.x; Xt[Kp] = c.y; Xt[2 * Kp] = c.th;
     }
@@ -115,10 +121,10 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     const float esum = wave_sum(e);
     el[lane] = e;
     __syncthreads();                                   // e in LDS; this wave's control stores visible to all its lanes
-    float *part = p.part + ((size_t)b * p.nblk + blockIdx.x) * (2 + 2 * T);
+    float *part = p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T);
     if (lane == 0) { part[0] = zmax; part[1] = esum; }
     // weighted control sums: lane = column j, whose 64 rollout values are one contiguous row of the (T,2,Kp) buffer
-    const float *Urow0 = p.U + (size_t)b * T * 2 * Kp + (size_t)blockIdx.x * kRolloutsPerBlock;
+    const float *Urow0 = p.U + (size_t)b * T * 2 * Kp + (size_t)wg.blk * kRolloutsPerBlock;
     for (int j = lane; j < 2 * T; j += 64) {
         const float4 *row = reinterpret_cast<const float4 *>(Urow0 + (size_t)j * Kp);
         float acc = 0.0f;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
 template <int EPS, int GEO>
 hipError_t launch_wave_g(const SolveParams &p, hipStream_t s)
 {
-    const dim3 grid(p.nblk + (p.have_prev ? 1 : 0), p.B);
+    const dim3 grid = rollout_grid(p, p.have_prev != 0);
     const size_t lds = wave_lds_bytes(p);
     if (p.WN > 0) {
         hipError_t e = ensure_lds(rollout_wave_kernel<EPS, GEO, true>, lds);

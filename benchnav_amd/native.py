@@ -31,7 +31,8 @@ class NativeMPPI:
                  sigmas=(0.5, 0.5), inv_var=None, lambda_: float = 0.5, u_min=(0.0, -1.0), u_max=(1.0, 1.0),
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
-                 profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False, kernel: str = "auto"):
+                 profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False, kernel: str = "auto",
+                 lean: bool = False):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -59,6 +60,7 @@ class NativeMPPI:
                      | (_capi.BN_FLAG_PRIVATE_STREAM if stream is None else 0)
                      | (0 if pipeline else _capi.BN_FLAG_NO_PIPELINE)
                      | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0)
+                     | (_capi.BN_FLAG_LEAN if lean else 0)
                      | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
@@ -266,6 +268,10 @@ class NativeMPPI:
         w = np.empty(n, np.float32)
         _capi.check(self._lib.bn_mppi_get_top_samples(self._h, instance, n, _fp(s), _fp(w)))
         return s, w
+
+    def reroll_async_device(self, out_ptr: int, n: int, idx_ptr: Optional[int] = None, instance: int = 0):
+        """Rows idx[0..n) (None: 0..n-1) of the latest solve's trajectory batch, regenerated into out (n,T+1,3) on the device."""
+        _capi.check(self._lib.bn_mppi_reroll_async(self._h, instance, C.c_void_p(idx_ptr), n, C.c_void_p(out_ptr)))
 
     def device_buffer(self, buf_id: int):
         ptr, nbytes = C.c_void_p(), C.c_size_t()

@@ -49,6 +49,19 @@ def gather_throughput(local_solves: int, local_seconds: float, device: Optional[
             "per_rank_solves": rows[:, 0].tolist(), "per_rank_seconds": rows[:, 1].tolist()}
 
 
+def gather_times(local_seconds, device: Optional[torch.device] = None, group=None) -> torch.Tensor:
+    """All-gather every rank's vector of timed-region durations (one per repeat) -> (world, repeats) float64 on the CPU.
+    The slowest rank bounds each repeat: whole-job time of repeat r = result[:, r].max().  Same transport rules as
+    gather_throughput (no group: one row; gloo: CPU tensors; nccl/RCCL: tensors on `device`)."""
+    import torch.distributed as dist
+    mine = torch.tensor([float(x) for x in local_seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    if not (dist.is_available() and dist.is_initialized()):
+        return mine.view(1, -1).cpu()
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return torch.stack(out).cpu()
+
+
 # ---------------------------------------------------------------------------------------------
 # Optional: ONE solve sharded over the ranks (SURVEY.md 8(e), config 5: K=16384 -> 2048 rollouts per GPU).
 # The only exchange is an all-gather of the per-workgroup softmin partials (max z, sum e, sum e*u): (2 + 2T) floats
@@ -93,19 +106,20 @@ class ShardedMPPI:
         self.world = self._dist.get_world_size(group) if self._dist else 1
         self.rank = self._dist.get_rank(group) if self._dist else 0
         self.first, self.count = shard_rollouts(num_samples, self.world, self.rank)
-        planner_kw.setdefault("stream", torch.cuda.current_stream().cuda_stream)
+        # one process per GPU: the planner, its stream and every tensor handed to it live on THIS rank's current device
+        self.device = torch.device("cuda", planner_kw.setdefault("device_id", torch.cuda.current_device()))
+        planner_kw.setdefault("stream", torch.cuda.current_stream(self.device).cuda_stream)
         self.planner = NativeMPPI(horizon=horizon, num_samples=self.count, grid_size=grid_size, resolution=resolution,
                                   num_instances=1, **planner_kw)
         self.planner.set_rollout_offset(self.first)
         self.T, self.K = horizon, num_samples
         self._counts = [shard_rollouts(num_samples, self.world, r)[1] // 64 for r in range(self.world)]
-        self._gathered = torch.empty(sum(self._counts), 2 + 2 * horizon, dtype=torch.float32, device="cuda")
+        self._gathered = torch.empty(sum(self._counts), 2 + 2 * horizon, dtype=torch.float32, device=self.device)
         self._host_backend = bool(self._dist) and self._dist.get_backend(group) != "nccl"
 
-    @staticmethod
-    def _view(ptr, shape):
+    def _view(self, ptr, shape):
         from .mppi import _DevArray
-        return torch.as_tensor(_DevArray(ptr, shape), device="cuda")
+        return torch.as_tensor(_DevArray(ptr, shape), device=self.device)
 
     def _partials_tensor(self):
         ptr, n, ps = self.planner.shard_partials()
@@ -125,7 +139,7 @@ class ShardedMPPI:
             # equal-sized all-gather (ragged shards are padded to the largest), then the valid rows in rank order
             maxc = max(self._counts)
             host = self._host_backend                    # gloo rehearsal: stage through the host
-            send = torch.zeros(maxc, mine.shape[1], dtype=torch.float32, device="cpu" if host else "cuda")
+            send = torch.zeros(maxc, mine.shape[1], dtype=torch.float32, device="cpu" if host else self.device)
             send[:mine.shape[0]].copy_(mine)
             recv = torch.empty(self.world * maxc, mine.shape[1], dtype=torch.float32, device=send.device)
             self._dist.all_gather_into_tensor(recv, send, group=self.group)      # RCCL over xGMI with backend "nccl"

@@ -74,6 +74,9 @@ enum {
     BN_FLAG_NO_PIPELINE = 1u << 5,     /* always two launches per solve (rollout, finish); see bn_mppi_solve_async */
     BN_FLAG_WAVE_KERNEL = 1u << 7,     /* always use the one-wave-per-64-rollouts throughput kernel (default: chosen by launch size) */
     BN_FLAG_ROLE_KERNEL = 1u << 8,     /* always use the five-wave role-split latency kernel */
+    BN_FLAG_LEAN = 1u << 9,            /* lean mode: _state_seq_batch (mppi.py:119-125) is not materialised -- 70 % of a solve's
+                                          HBM bytes; bn_mppi_get_states / bn_mppi_get_top_samples / bn_mppi_reroll_async
+                                          regenerate the requested rows of the latest solve bit-identically on demand */
     BN_FLAG_SAMPLED_SLIP = 1u << 6     /* BASELINE config 3: every traversability lookup of the rollouts draws
                                           slip ~ Normal(map, slip_std)[cell]; see bn_mppi_set_slip_std */
 };
@@ -255,6 +258,12 @@ int bn_mppi_get_slip_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_index,
  * by weight descending.  states_host (n,T+1,3), weights_host (n,).  n <= K. */
 int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *states_host,
                             float *weights_host);
+
+/* Rows of the LATEST solve's _state_seq_batch regenerated on the device (works in every mode but sampled-slip; it is how
+ * lean mode serves get_top_samples, mppi.py:232-238): rollouts idx_device[0..n) (NULL: rollouts 0..n-1) -> out_device
+ * (n,T+1,3), bit-identical to the rows a full-API solve stores (same noise, mean, start state, device functions).
+ * Writes the pending tail first; with injected noise the caller's eps block of that solve must still be alive. */
+int bn_mppi_reroll_async(bn_mppi_t *h, int32_t instance, const int32_t *idx_device, int32_t n, float *out_device);
 
 /* Zero-copy access to a library-owned device buffer (layouts in bn_buffer_id). */
 int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size_t *bytes);
