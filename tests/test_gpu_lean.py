@@ -145,16 +145,18 @@ def test_failed_create_frees_everything_it_allocated():
     (VERDICT r1 item 8).  A handle that cannot be allocated must leave the device's free memory where it was."""
     import torch
     from benchnav_amd import NativeMPPI, _capi
+    with pytest.raises(_capi.BenchnavError):               # first failure also settles the runtime's own lazy allocations
+        NativeMPPI(grid_size=64, resolution=0.5, shared_map=True, num_samples=16384, horizon=100, num_instances=20000)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
-    for kw in (dict(num_samples=16384, horizon=100, num_instances=20000),                      # the trajectory batch alone is ~400 TB
-               dict(num_samples=16384, horizon=100, num_instances=20000, lean=True),           # lean: fails later, at the cost / partial buffers
-               dict(num_samples=8192, horizon=50, num_instances=30000, sampled_slip=True)):
+    for kw in (dict(num_samples=16384, horizon=100, num_instances=20000),                      # the trajectory batch alone is ~400 GB
+               dict(num_samples=262144, horizon=100, num_instances=32768, lean=True),          # lean: 2 x 34 GB of costs fit, the partials (108 TB) do not
+               dict(num_samples=16384, horizon=50, num_instances=32768, sampled_slip=True)):         # 328 GB of trajectories
         with pytest.raises(_capi.BenchnavError) as ei:
             NativeMPPI(grid_size=64, resolution=0.5, shared_map=True, **kw)
         assert ei.value.code == _capi.BN_ERR_HIP
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
-    assert abs(free1 - free0) < 64 << 20, (free0, free1)
+    assert abs(free1 - free0) < 256 << 20, (free0, free1)
     with NativeMPPI(horizon=20, num_samples=128, grid_size=64, resolution=0.5) as pl:          # the device is still usable
         assert pl.solve_count() == 0
