@@ -17,7 +17,7 @@ BN_ERR_INVALID, BN_ERR_HIP, BN_ERR_NO_DEVICE, BN_ERR_STATE = -1, -2, -3, -4
 BN_NOISE_PHILOX, BN_NOISE_HOST_KT2, BN_NOISE_DEVICE_KT2, BN_NOISE_DEVICE_T2K = 0, 1, 2, 3
 BN_MEM_HOST, BN_MEM_DEVICE = 0, 1
 (BN_BUF_STATES, BN_BUF_WEIGHTS, BN_BUF_COSTS, BN_BUF_CONTROLS, BN_BUF_USTAR, BN_BUF_XSTAR,
- BN_BUF_MEAN, BN_BUF_MAP, BN_BUF_GOAL) = range(9)
+ BN_BUF_MEAN, BN_BUF_MAP, BN_BUF_GOAL, BN_BUF_USTAR_XSTAR) = range(10)
 BN_FLAG_STORE_CONTROLS, BN_FLAG_SHARED_MAP, BN_FLAG_NO_LDS_WINDOW, BN_FLAG_PROFILE, BN_FLAG_PRIVATE_STREAM = 1, 2, 4, 8, 16
 BN_FLAG_NO_PIPELINE = 32
 BN_FLAG_SAMPLED_SLIP = 64
@@ -56,12 +56,14 @@ SYMBOLS = {
     "bn_mppi_get_mean": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_solve": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, _FP, _FP]),
     "bn_mppi_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "bn_mppi_forward_async": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),
     "bn_mppi_solve_n_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64]),
     "bn_mppi_set_rollout_offset": (C.c_int, [_H, C.c_int64]),
     "bn_mppi_shard_rollout_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_shard_partials": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bn_mppi_shard_finish_async": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "bn_mppi_env_attach": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint64]),
+    "bn_mppi_env_set_freeze": (C.c_int, [_H, C.c_int32]),
     "bn_mppi_env_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bn_mppi_env_collision_check": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p]),
     "bn_mppi_episode_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_void_p]),

@@ -134,6 +134,7 @@ size_t buffer_bytes(const bn_mppi *h, bn_buffer_id id)
     case BN_BUF_MEAN: return B * T * 2 * 4;
     case BN_BUF_MAP: return (size_t)h->n_maps * G * G * 4;
     case BN_BUF_GOAL: return B * 2 * 4;
+    case BN_BUF_USTAR_XSTAR: return (B * T * 2 + B * (T + 1) * 3) * 4;
     default: return 0;
     }
 }
@@ -317,8 +318,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     }
     alloc(&h->d_cost_out, B * K * 4);
     alloc(&h->d_w, B * K * 4);
-    alloc(&h->d_ustar, B * T * 2 * 4);
-    alloc(&h->d_xstar, B * (T + 1) * 3 * 4);
+    alloc(&h->d_ustar, (B * T * 2 + B * (T + 1) * 3) * 4);   // U* then X* in ONE block (BN_BUF_USTAR_XSTAR): a caller copies both at once
+    if (h->d_ustar) h->d_xstar = h->d_ustar + B * T * 2;
     alloc(&h->d_stats, B * 2 * 4);
     if (rc == BN_OK && hipHostMalloc((void **)&h->h_pinned, B * 3 * 4, hipHostMallocDefault) != hipSuccess)
         rc = fail(BN_ERR_HIP, "hipHostMalloc failed");
@@ -384,7 +385,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1],
                     h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
-                    h->d_w, h->d_ustar, h->d_xstar, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
+                    h->d_w, h->d_ustar /* d_xstar lives in the same block */, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
                     h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket, h->d_gpart, h->d_mean_used};
     for (void *b : bufs)
@@ -625,6 +626,15 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     return solve_impl(h, states, states_where, eps, noise, false);
 }
 
+int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise)
+{
+    // MPPI.forward as ONE call for a host loop that consumes every solve's outputs (test_mppi.py:174-183): the solve and
+    // its tail, both only enqueued; U*, X*, weights are in the device buffers in stream order.
+    if (int rc = solve_impl(h, states_device, BN_MEM_DEVICE, eps_device, noise, false)) return rc;
+    BN_BIND(h);
+    return flush_tail(h);
+}
+
 int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
@@ -704,6 +714,15 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
     h->p.lat_mean = h->d_lat_mean; h->p.lat_std = h->d_lat_std; h->p.env_state = h->d_env_state; h->p.ep_done = h->d_ep_done;
     h->p.goal_thr = goal_threshold; h->p.env_dt = delta_t; h->p.env_seed = seed;
     h->env_attached = true;
+    return BN_OK;
+}
+
+int bn_mppi_env_set_freeze(bn_mppi_t *h, int32_t freeze_on_goal)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    BN_BIND(h);
+    if (int rc = flush_tail(h)) return rc;
+    h->p.env_freeze = freeze_on_goal ? 1 : 0;
     return BN_OK;
 }
 
@@ -1017,7 +1036,7 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
 int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size_t *bytes)
 {
     if (!h || !device_ptr) return fail(BN_ERR_INVALID, "null argument");
-    void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost_out, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal};
+    void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost_out, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal, h->d_ustar};
     if ((int)id < 0 || id >= BN_BUF_COUNT_) return fail(BN_ERR_INVALID, "unknown buffer id %d", (int)id);
     *device_ptr = ptrs[id];
     if (bytes) *bytes = buffer_bytes(h, id);

@@ -190,7 +190,8 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
 
 // One PlanetaryEnv.step (planetary_env.py:189-219) for instance b: observation-mode transit with the
 // latent slip sampled at the current cell (traversability_model.py:65-69: Normal(mean, std)[cell].sample()
-// = z * std + mean), then the goal test.  An instance already within goal_thr of its goal is frozen.
+// = z * std + mean), then the goal test.  Like the reference, a terminated environment keeps moving when stepped again;
+// with p.env_freeze (opt-in, for fixed-length batched episodes) an instance already within goal_thr of its goal stays put.
 // Every workgroup that needs the next state evaluates this itself: same inputs, same operations.
 struct EnvStep { float x, y, th, reward; bool reached, frozen; };
 
@@ -201,7 +202,7 @@ __device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, floa
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
     EnvStep r;
     const float d0x = sx - gx, d0y = sy - gy;
-    r.frozen = sqrt_cr(d0x * d0x + d0y * d0y) < p.goal_thr;          // terminated at an earlier step
+    r.frozen = p.env_freeze && sqrt_cr(d0x * d0x + d0y * d0y) < p.goal_thr;      // terminated at an earlier step
     const int ix = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
     const int iy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
     const size_t cell = (size_t)b * p.map_stride + (size_t)iy * p.G + ix;

@@ -60,6 +60,8 @@ struct SolveParams {
     int env_on;          // the tail logs the environment step that follows its solve
     int ep_index;        // episode index of the solve whose tail this launch writes = index of the env step the
                          // rollout workgroups apply in closed-loop mode (the step after that solve)
+    int env_freeze;      // opt-in (bn_mppi_env_set_freeze): an environment within goal_thr of its goal stays where it is; the
+                         // reference keeps stepping a terminated environment (its driver loop stops instead, test_mppi.py:192-194)
     float goal_thr;      // PlanetaryEnv goal_threshold (planetary_env.py:215-217)
     float env_dt;        // PlanetaryEnv delta_t passed to transit (planetary_env.py:203-205)
     uint64_t env_seed;

@@ -50,7 +50,9 @@ class DWA(nn.Module):
                                   x_limits=inp["x_limits"], y_limits=inp["y_limits"],
                                   u_min=self._u_min.tolist(), u_max=self._u_max.tolist(),
                                   stuck_threshold=inp["stuck_threshold"], device_id=self._device.index, stream=0)
-        self._native.set_map(inp["risks"].detach().to("cpu", torch.float32).numpy())
+        self._risk_cpu = inp["risks"].detach().to("cpu", torch.float32).contiguous()
+        self._grid = (inp["grid_size"], inp["resolution"], inp["x_limits"], inp["y_limits"])
+        self._native.set_map(self._risk_cpu.numpy())
         self._native.set_goal(self._goal.numpy())
         n = num_lin_vel * num_ang_vel
         self._previous_action_seq = torch.zeros(horizon, dim_control, device=self._device, dtype=dtype)
@@ -82,6 +84,23 @@ class DWA(nn.Module):
             return path[torch.where(dist == nearest)[0][0]]
         return path[-1]
 
+    def _sub_goal_state(self, state: torch.Tensor, action0: torch.Tensor) -> torch.Tensor:
+        """The state the reference's sub-goal rule sees.  _compute_costs calls _select_sub_goal(state_seq_batch[0, 0, :])
+        AFTER the rollouts (dwa.py:240-244), and transit's in-place `x +=` / `theta +=` (robot_model.py:86-88) has by then
+        turned candidate 0's slot 0 into the input state advanced by one un-clamped, un-wrapped step of candidate 0.
+        Same torch-CPU operations in the same order as robot_model.py:75-88 / grid_map.py:195-209 (transit's default
+        delta_t = 0.1: DWA does not pass its own)."""
+        G, res, xl, yl = self._grid
+        origin = torch.tensor([xl[0], yl[0]], dtype=self._dtype)
+        idx = ((state[:2] - origin) / res).floor().int().clamp(0, G - 1)
+        trav = 1 - torch.clamp(self._risk_cpu[idx[1], idx[0]], 0, 1)
+        v = torch.clamp(action0[0], self._u_min[0], self._u_max[0])
+        omega = torch.clamp(action0[1], self._u_min[1], self._u_max[1])
+        x = state[0] + trav * v * torch.cos(state[2]) * 0.1
+        y = state[1] + trav * v * torch.sin(state[2]) * 0.1
+        theta = state[2] + trav * omega * 0.1
+        return torch.stack([x, y, theta])
+
     def update_reference_path(self, reference_path: torch.Tensor) -> None:
         if reference_path is not None:
             assert reference_path.shape[1] == 2, "reference_path must be a tensor of shape (num_positions, 2)"
@@ -95,7 +114,7 @@ class DWA(nn.Module):
         assert state.shape == (self._dim_state,), "state must be a tensor of shape (dim_state,)"
         st = state.detach().to("cpu", self._dtype)
         actions = self._generate_actions()
-        sub_goal = self._select_sub_goal(st) if self.reference_path is not None else None
+        sub_goal = self._select_sub_goal(self._sub_goal_state(st, actions[0])) if self.reference_path is not None else None
         out = self._native.dwa_solve(st.numpy(), actions.numpy(), None if sub_goal is None else sub_goal.numpy(), full=False)
         best = int(out["best_index"][0])
         n = actions.shape[0]

@@ -20,6 +20,15 @@ import torch.nn as nn
 from . import _capi
 
 
+class _CallState:
+    """Per-call state of MPPI.forward.  A plain object: nn.Module.__setattr__ inspects every assignment (parameters,
+    buffers, sub-modules), which costs microseconds per attribute in a loop that runs once per control step."""
+    __slots__ = ("eps", "noise_cache", "rolled", "state")
+
+    def __init__(self):
+        self.eps = self.noise_cache = self.rolled = self.state = None
+
+
 class _DevArray:
     """Library-owned device memory exposed to torch through __cuda_array_interface__."""
 
@@ -69,14 +78,20 @@ class MPPI(nn.Module):
                       (traversability_model.py:65-69).  The reference's own MPPI cannot (its transit returns a tuple
                       there), so this is opt-in; without it observation-mode dynamics raise TypeError as in the reference.
       store_controls  keep `_perturbed_action_seqs` in HBM (the reference always has it).
-      copy_outputs    return fresh tensors from forward() like the reference; False returns
-                      views of the planner's buffers (overwritten by the next call).
+      copy_outputs    return fresh tensors from forward() like the reference (ONE device copy of the packed U* | X*
+                      block); False returns views of the planner's buffers (overwritten by the next call).
+      lean            do not materialise `_state_seq_batch` (70 % of a solve's HBM bytes): get_top_samples re-rolls the
+                      winners on demand and `_state_seq_batch` re-rolls all K rows when it is read, bit-identical either way.
+
+    Streams: the planner enqueues on the torch stream that was current for its device at construction.  forward() called
+    under another current stream fences the two with events (correct, slower); keep one stream for the best latency.
     """
 
     def __init__(self, horizon: int, num_samples: int, dim_state: int, dim_control: int, dynamics, objectives,
                  sigmas: torch.Tensor, lambda_: float, device=torch.device("cuda"), dtype=torch.float32,
                  seed: int = 42, *, noise: str = "torch_device", store_controls: bool = True,
-                 copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1, sampled_slip: bool = False) -> None:
+                 copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1, sampled_slip: bool = False,
+                 lean: bool = False) -> None:
         super().__init__()
         torch.manual_seed(seed)                                    # mppi.py:55
 
@@ -134,9 +149,11 @@ class MPPI(nn.Module):
         cfg.lambda_, cfg.dt, cfg.stuck_threshold = lambda_, delta_t, inp["stuck_threshold"]
         cfg.seed = seed
         cfg.flags = ((_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0) | (_capi.BN_FLAG_PROFILE if profile else 0)
-                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0))
+                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0) | (_capi.BN_FLAG_LEAN if lean else 0))
+        self._lean = bool(lean)
         with torch.cuda.device(dev):
-            cfg.stream = torch.cuda.current_stream(dev).cuda_stream
+            self._stream = torch.cuda.current_stream(dev)
+            cfg.stream = self._stream.cuda_stream
             self._handle = C.c_void_p()
             _capi.check(lib.bn_mppi_create(C.byref(cfg), C.byref(self._handle)))
         self._lib = lib
@@ -152,21 +169,24 @@ class MPPI(nn.Module):
 
         K, T = num_samples, horizon
         Kp = int(lib.bn_mppi_row_pitch(self._handle))        # rows are pitched to 64*ceil(K/64) floats
-        self._buf_X = self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, Kp))[:, :, :K]
+        self._buf_X = None if lean else self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, Kp))[:, :, :K]
         self._buf_w = self._wrap(_capi.BN_BUF_WEIGHTS, (K,))
         self._buf_cost = self._wrap(_capi.BN_BUF_COSTS, (K,))
         self._buf_U = self._wrap(_capi.BN_BUF_CONTROLS, (T, 2, Kp))[:, :, :K] if store_controls else None
-        self._buf_ustar = self._wrap(_capi.BN_BUF_USTAR, (T, 2))
-        self._buf_xstar = self._wrap(_capi.BN_BUF_XSTAR, (1, T + 1, 3))
+        self._buf_out = self._wrap(_capi.BN_BUF_USTAR_XSTAR, (T * 2 + (T + 1) * 3,))     # U* | X*, one block
+        self._buf_ustar = self._buf_out[:T * 2].view(T, 2)
+        self._buf_xstar = self._buf_out[T * 2:].view(1, T + 1, 3)
+        self._fwd = lib.bn_mppi_forward_async                   # bound once: forward() is a host hot loop
+        self._h = self._handle.value
+
         self._buf_mean = self._wrap(_capi.BN_BUF_MEAN, (T, 2))
-        self._eps_dev: Optional[torch.Tensor] = None
-        self._noise_cache: Optional[torch.Tensor] = None
+        self._cs = _CallState()
 
         if noise == "torch":
             # the reference constructor consumes one (K,T,2) draw of the global CPU stream (mppi.py:105-107)
-            self._noise_cache = torch.empty(K, T, 2).normal_() * s_cpu
+            self._cs.noise_cache = torch.empty(K, T, 2).normal_() * s_cpu
         elif noise == "torch_device":
-            self._noise_cache = torch.randn(K, T, 2, device=dev) * self._sigmas
+            self._cs.noise_cache = torch.randn(K, T, 2, device=dev) * self._sigmas
 
     # -- plumbing ------------------------------------------------------------------
     def _wrap(self, buf_id, shape):
@@ -212,8 +232,19 @@ class MPPI(nn.Module):
 
     @property
     def _state_seq_batch(self) -> torch.Tensor:
-        """(K, T+1, 3) view of the planner-native (T+1, 3, K) buffer (no copy)."""
+        """(K, T+1, 3): a view of the planner-native (T+1, 3, K) buffer (no copy); in lean mode the rows are re-rolled
+        on first access after a forward() (bit-identical to what a full-API solve stores)."""
+        if self._lean:
+            if self._cs.rolled is None:
+                self._cs.rolled = self._reroll(None, self._num_samples)
+            return self._cs.rolled
         return self._buf_X.permute(2, 0, 1)
+
+    def _reroll(self, idx: Optional[torch.Tensor], n: int) -> torch.Tensor:
+        out = torch.empty(n, self._horizon + 1, 3, device=self._device, dtype=self._dtype)
+        with self._on_planner_stream():
+            _capi.check(self._lib.bn_mppi_reroll_async(self._handle, 0, None if idx is None else idx.data_ptr(), n, out.data_ptr()))
+        return out
 
     @property
     def _weights(self) -> torch.Tensor:
@@ -230,6 +261,26 @@ class MPPI(nn.Module):
         return self._buf_U.permute(2, 0, 1)
 
     # -- the solve ---------------------------------------------------------------------
+    class _Fence:
+        """Orders torch's current stream and the planner's stream around a library call when they differ."""
+
+        def __init__(self, owner):
+            self.o = owner
+            self.cur = torch.cuda.current_stream(owner._device)
+            self.same = self.cur.cuda_stream == owner._stream.cuda_stream
+
+        def __enter__(self):
+            if not self.same:
+                self.o._stream.wait_stream(self.cur)         # inputs produced on the current stream
+            return self
+
+        def __exit__(self, *exc):
+            if not self.same:
+                self.cur.wait_stream(self.o._stream)         # outputs consumed on the current stream
+
+    def _on_planner_stream(self):
+        return MPPI._Fence(self)
+
     def forward(self, state: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Solve the optimal control problem (mppi.py:130-219).
 
@@ -239,25 +290,32 @@ class MPPI(nn.Module):
         if not torch.is_tensor(state):
             state = torch.tensor(state, dtype=self._dtype)
         assert state.shape == (self._dim_state,)
-        st = state.detach().to(self._device, self._dtype).contiguous()
-        K, T = self._num_samples, self._horizon
-        if self._noise_mode == "torch":
-            eps = torch.empty(K, T, 2).normal_()                       # global CPU stream, mppi.py:149-151
-            self._eps_dev = eps.to(self._device)
-            kind, eptr = _capi.BN_NOISE_DEVICE_KT2, C.c_void_p(self._eps_dev.data_ptr())
-        elif self._noise_mode == "torch_device":
-            self._eps_dev = torch.randn(K, T, 2, device=self._device)
-            kind, eptr = _capi.BN_NOISE_DEVICE_KT2, C.c_void_p(self._eps_dev.data_ptr())
+        if state.device != self._device or state.dtype != self._dtype or not state.is_contiguous():
+            state = state.detach().to(self._device, self._dtype).contiguous()
+        mode = self._noise_mode
+        if mode == "philox":
+            eps, eptr, kind = None, None, _capi.BN_NOISE_PHILOX
         else:
-            self._eps_dev = None
-            kind, eptr = _capi.BN_NOISE_PHILOX, C.c_void_p(None)
-        self._noise_cache = None                                       # _action_noises is derived on demand
-        self._last_state = st                                          # keep alive until the kernels ran
-        _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
-                                                  eptr, kind))
-        _capi.check(self._lib.bn_mppi_flush(self._handle))            # U*, X*, weights of THIS solve, stream-ordered
+            K, T = self._num_samples, self._horizon
+            if mode == "torch":
+                eps = torch.empty(K, T, 2).normal_().to(self._device)      # global CPU stream, mppi.py:149-151
+            else:
+                eps = torch.randn(K, T, 2, device=self._device)
+            eptr, kind = eps.data_ptr(), _capi.BN_NOISE_DEVICE_KT2
+        cs = self._cs
+        cs.eps, cs.noise_cache, cs.rolled = eps, None, None           # _action_noises and lean rows are derived on demand
+        cs.state = state                                               # keep alive until the kernels ran
+        if torch.cuda.current_stream(self._device).cuda_stream == self._stream.cuda_stream:
+            rc = self._fwd(self._h, state.data_ptr(), eptr, kind)      # solve + tail: U*, X*, weights of THIS solve, stream-ordered
+        else:
+            with self._on_planner_stream():
+                rc = self._fwd(self._h, state.data_ptr(), eptr, kind)
+        if rc:
+            _capi.check(rc)
         if self._copy_outputs:
-            return self._buf_ustar.clone(), self._buf_xstar.clone()
+            T = self._horizon
+            out = self._buf_out.clone()                                # one device copy for both outputs
+            return out[:T * 2].view(T, 2), out[T * 2:].view(1, T + 1, 3)
         return self._buf_ustar, self._buf_xstar
 
     solve = forward
@@ -266,27 +324,30 @@ class MPPI(nn.Module):
     def _action_noises(self) -> Optional[torch.Tensor]:
         """The reference's `_action_noises` (eps * sigma, mppi.py:149-151) of the latest forward(); None with
         in-kernel noise.  Derived on demand: the planner consumes eps itself."""
-        if self._noise_cache is None and self._eps_dev is not None:
-            self._noise_cache = self._eps_dev * self._sigmas
-        return self._noise_cache
+        cs = self._cs
+        if cs.noise_cache is None and cs.eps is not None:
+            cs.noise_cache = cs.eps * self._sigmas
+        return cs.noise_cache
 
     def solve_with_noise(self, state: torch.Tensor, eps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """forward() with caller-supplied standard-normal noise eps (K,T,2) (teacher-forced parity tests)."""
         assert eps.shape == (self._num_samples, self._horizon, 2)
         st = torch.as_tensor(state).detach().to(self._device, self._dtype).contiguous()
-        self._eps_dev = eps.detach().to(self._device, self._dtype).contiguous()
-        self._noise_cache = None
-        self._last_state = st
-        _capi.check(self._lib.bn_mppi_solve_async(self._handle, C.c_void_p(st.data_ptr()), _capi.BN_MEM_DEVICE,
-                                                  C.c_void_p(self._eps_dev.data_ptr()), _capi.BN_NOISE_DEVICE_KT2))
-        _capi.check(self._lib.bn_mppi_flush(self._handle))
+        cs = self._cs
+        cs.eps = eps.detach().to(self._device, self._dtype).contiguous()
+        cs.noise_cache, cs.rolled, cs.state = None, None, st
+        with self._on_planner_stream():
+            _capi.check(self._fwd(self._h, st.data_ptr(), cs.eps.data_ptr(), _capi.BN_NOISE_DEVICE_KT2))
         return self._buf_ustar.clone(), self._buf_xstar.clone()
 
     def get_top_samples(self, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """The `num_samples` highest-weight rollouts, by weight descending (mppi.py:221-240)."""
         assert num_samples <= self._num_samples
         top_indices = torch.topk(self._weights, num_samples).indices
-        top_samples = self._state_seq_batch[top_indices]
+        if self._lean and self._cs.rolled is None:                     # lean: only the winners are re-rolled
+            top_samples = self._reroll(top_indices.to(torch.int32), num_samples)
+        else:
+            top_samples = self._state_seq_batch[top_indices]
         top_weights = self._weights[top_indices]
         order = torch.argsort(top_weights, descending=True)
         return top_samples[order], top_weights[order]

@@ -64,6 +64,7 @@ class NativeMPPI:
                      | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
+        self.device_id, self.stream = device_id, stream       # stream: the hipStream_t the handle enqueues on (None: private)
         self.store_controls = store_controls
         self._shared_map = shared_map or num_instances == 1
         self._ep_steps = 0
@@ -195,9 +196,11 @@ class NativeMPPI:
         return x.value, c.value, w.value
 
     # -- device-side closed loop (PlanetaryEnv.step between solves) ------------------------------
-    def env_attach(self, latent_mean, latent_std, goal_threshold: float = 1.0, delta_t: float = 0.1, seed: int = 0):
+    def env_attach(self, latent_mean, latent_std, goal_threshold: float = 1.0, delta_t: float = 0.1, seed: int = 0,
+                   freeze_on_goal: bool = False):
         """Latent slip model Normal(mean, std) per cell ((G,G) shared or (n_maps,G,G)), PlanetaryEnv defaults
-        (planetary_env.py:36: goal_threshold=1.0)."""
+        (planetary_env.py:36: goal_threshold=1.0).  freeze_on_goal: an instance within goal_threshold stays put (opt-in;
+        the reference environment keeps moving when a terminated episode is stepped)."""
         n_maps = 1 if self._shared_map else self.B
         m = _f32(latent_mean).reshape(-1, self.G, self.G)
         s = _f32(latent_std).reshape(-1, self.G, self.G)
@@ -206,6 +209,7 @@ class NativeMPPI:
         assert m.shape == (n_maps, self.G, self.G) and s.shape == m.shape
         _capi.check(self._lib.bn_mppi_env_attach(self._h, C.c_void_p(m.ctypes.data), C.c_void_p(s.ctypes.data),
                                                  _capi.BN_MEM_HOST, goal_threshold, delta_t, seed))
+        _capi.check(self._lib.bn_mppi_env_set_freeze(self._h, 1 if freeze_on_goal else 0))
 
     def episode(self, n_steps: int, states0, z_device_ptr: Optional[int] = None, eps_ptr: Optional[int] = None,
                 kind: int = _capi.BN_NOISE_PHILOX, eps_ring: int = 1, eps_stride: int = 0, wait: bool = True):

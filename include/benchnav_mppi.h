@@ -62,7 +62,9 @@ typedef enum bn_buffer_id {
     BN_BUF_MEAN = 6,      /* (B,T,2)      _previous_action_seq                                 */
     BN_BUF_MAP = 7,       /* (n_maps,G,G) risk map(s)                                          */
     BN_BUF_GOAL = 8,      /* (B,2)                                                             */
-    BN_BUF_COUNT_ = 9
+    BN_BUF_USTAR_XSTAR = 9, /* the (B,T,2) U* block followed by the (B,T+1,3) X* block: both outputs of forward() are one
+                               contiguous allocation, so a caller that wants private copies makes ONE device copy     */
+    BN_BUF_COUNT_ = 10
 } bn_buffer_id;
 
 enum {
@@ -164,6 +166,9 @@ int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, c
  * bn_mppi_device_buffer are up to date after bn_mppi_sync (or bn_mppi_flush + stream order). */
 int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where,
                         const float *eps, bn_noise_kind noise);
+/* MPPI.forward (mppi.py:130-219) for a host loop that consumes every solve (test_mppi.py:174-183): bn_mppi_solve_async +
+ * bn_mppi_flush in one call.  states_device (B,3) and eps_device are device pointers; nothing is copied, nothing waits. */
+int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise);
 /* n dependent solves enqueued from one call (the warm start chains them on the device; the state is
  * re-read from `states` by every solve, so a device-resident state may be advanced in between by
  * other work on the same stream).  Noise block i is eps + (i % eps_ring) * eps_stride floats. */
@@ -190,8 +195,10 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
  *                ["latent_models"], sampled in observation mode: traversability_model.py:65-69),
  *                goal_threshold (planetary_env.py:215-217), the environment's delta_t, Philox key.
  *   episode      n_steps control steps: solve at the current state, apply U*[0] through the observation-mode
- *                transit with a freshly sampled slip, test the goal; an instance that has reached its goal
- *                stays frozen.  z_device: optional (n_steps, B) standard normals for the slip draws (parity
+ *                transit with a freshly sampled slip, test the goal.  Like PlanetaryEnv.step, a terminated
+ *                environment keeps moving when stepped (the reference's driver loop stops instead,
+ *                test_mppi.py:192-194); bn_mppi_env_set_freeze(h, 1) opts into freezing an instance once it is
+ *                within goal_threshold, for fixed-length batched episodes.  z_device: optional (n_steps, B) standard normals for the slip draws (parity
  *                tests), NULL = in-kernel Philox.  One launch per control step (K <= 2048 only).
  *   episode_log  states (n_steps+1, B, 3) incl. the initial one, rewards (n_steps, B) = traversability
  *                observed by each step (planetary_env.py:209), actions (n_steps, B, 2) = the control each step
@@ -203,11 +210,12 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
 /* The two PlanetaryEnv calls on their own, for callers that drive the loop themselves (all pointers device memory, stream-ordered):
  *   env_step             planetary_env.py:189-219 for the B environments: states (B,3) advance in place through the
  *                        observation-mode transit with actions (B,2); rewards (B,) = the sampled traversability;
- *                        terminated (B,) = within goal_threshold of the goal.  An environment that had already
- *                        terminated stays where it is.  z (B,) injects the slip draws, NULL = Philox keyed by
+ *                        terminated (B,) = within goal_threshold of the goal (a terminated environment moves on when
+ *                        stepped again, as the reference's does, unless bn_mppi_env_set_freeze).  z (B,) injects the slip draws, NULL = Philox keyed by
  *                        (env seed, step_index).
  *   env_collision_check  planetary_env.py:221-232: out (B,N) = sampled traversability at states (B,N,3) <= stuck_threshold,
  *                        one fresh draw per position (z (B,N) injects them; NULL = Philox keyed by (env seed, draw_index)). */
+int bn_mppi_env_set_freeze(bn_mppi_t *h, int32_t freeze_on_goal);      /* default 0 = the reference's behaviour */
 int bn_mppi_env_step(bn_mppi_t *h, const float *actions_device, float *states_device, float *rewards_device,
                      int32_t *terminated_device, const float *z_device, uint64_t step_index);
 int bn_mppi_env_collision_check(bn_mppi_t *h, const float *states_device, int32_t n_positions, float stuck_threshold,

@@ -113,6 +113,27 @@ def env_step(p: OracleParams, trav, state, u):
     return nxt
 
 
+def env_step_sampled(p: OracleParams, MU, SG, z, goal_thr, state, u):
+    """PlanetaryEnv.step (planetary_env.py:189-219) with the slip draw z explicit; p.dt is the environment's delta_t.
+    Returns (next_state (3,), reward, terminated)."""
+    MU = _f32(MU, (p.G, p.G)); SG = _f32(SG, (p.G, p.G)); state = _f32(state, (3,)); u = _f32(u, (2,))
+    nxt = np.empty(3, np.float32); rw = C.c_float(); term = C.c_int32()
+    lib().oracle_env_step_sampled(C.byref(p), _fp(MU), _fp(SG), C.c_float(z), C.c_float(goal_thr), _fp(state), _fp(u), _fp(nxt),
+                                  C.byref(rw), C.byref(term))
+    return nxt, np.float32(rw.value), bool(term.value)
+
+
+def collision_check(p: OracleParams, MU, SG, states, z, stuck_thr):
+    """PlanetaryEnv.collision_check (planetary_env.py:221-232): states (..., 3), z (...) -> bool (...)."""
+    MU = _f32(MU, (p.G, p.G)); SG = _f32(SG, (p.G, p.G))
+    st = _f32(states); zz = _f32(z)
+    assert st.shape[:-1] == zz.shape and st.shape[-1] == 3
+    out = np.empty(zz.size, np.uint8)
+    lib().oracle_collision_check(C.byref(p), _fp(MU), _fp(SG), _fp(st), _fp(zz), C.c_int64(zz.size), C.c_float(stuck_thr),
+                                 out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out.reshape(zz.shape).astype(bool)
+
+
 def sincos(x, trig=TRIG_SPEC):
     x = _f32(x).ravel()
     s = np.empty_like(x); c = np.empty_like(x)
@@ -129,6 +150,17 @@ def dwa(p: OracleParams, R, state, actions, sub_goal=None):
     lib().oracle_dwa.restype = C.c_int32
     best = lib().oracle_dwa(C.byref(p), _fp(R), _fp(state), _fp(actions), C.c_int32(NA), _fp(sg), _fp(X), _fp(cost), _fp(w))
     return dict(X=X, cost=cost, w=w, best=int(best))
+
+
+def dwa_sub_goal(p: OracleParams, R, state, action0, path, lookahead):
+    """The sub-goal DWA.forward uses (dwa.py:240-244, 260-285): picked from candidate 0's aliased slot-0 state.
+    Returns (sub_goal (2,), the state the rule saw (3,), index)."""
+    R = _f32(R, (p.G, p.G)); state = _f32(state, (3,)); a0 = _f32(action0, (2,)); path = _f32(path)
+    sel = np.empty(3, np.float32); sg = np.empty(2, np.float32)
+    lib().oracle_dwa_sub_goal.restype = C.c_int32
+    idx = lib().oracle_dwa_sub_goal(C.byref(p), _fp(R), _fp(state), _fp(a0), _fp(path), C.c_int32(path.shape[0]), C.c_float(lookahead),
+                                    _fp(sel), _fp(sg))
+    return sg, sel, int(idx)
 
 
 def solve_sampled(p: OracleParams, MU, SG, state, mean, eps, zt, zc, zo):

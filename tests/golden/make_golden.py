@@ -36,6 +36,15 @@ _stub = types.ModuleType("opensimplex")
 _stub.seed = lambda s: None
 _stub.noise2 = lambda x, y: 0.0
 sys.modules["opensimplex"] = _stub
+# PlanetaryEnv (planetary_env.py:10-14) imports gymnasium and imageio, absent here; it only subclasses gym.Env[...] and
+# uses imageio in close().  Stubs of the same kind as opensimplex's: nothing of the step / collision arithmetic is touched.
+_gym = types.ModuleType("gymnasium")
+_gym.Env = type("Env", (), {"__class_getitem__": classmethod(lambda cls, item: cls)})
+_gym.spaces = types.ModuleType("gymnasium.spaces")
+sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = _gym, _gym.spaces
+sys.modules["imageio"] = types.ModuleType("imageio")
+import matplotlib  # noqa: E402
+matplotlib.use("Agg")
 
 from torch.distributions import Normal  # noqa: E402
 from src.environments.grid_map import GridMap  # noqa: E402
@@ -151,8 +160,11 @@ def run_riskmap_case():
 
 
 def run_dwa_case():
-    """DWA (dwa.py:116-258): three consecutive forwards (dynamic window follows the previous action) with a
-    reference path, on the c1_stuck map."""
+    """DWA (dwa.py:116-258) with a reference path: three consecutive forwards (the dynamic window follows the previous
+    action) and five forwards from states placed next to the sub-goal rule's thresholds (look-ahead distance, +-90 degree
+    bearing, dwa.py:274-277).  The sub-goal stored is the one the reference USED: _compute_costs picks it from
+    state_seq_batch[0, 0, :] AFTER the rollouts (dwa.py:240-244), i.e. from candidate 0's slot 0, which transit's in-place
+    update has already advanced by one un-clamped, un-wrapped step (robot_model.py:86-88) -- not from the input state."""
     from src.planners.local_planners.dwa import DWA
     G, res, T = 64, 0.5, 20
     goal = torch.tensor([24.0, 24.0])
@@ -161,25 +173,58 @@ def run_dwa_case():
                  delta_t=0.1, lookahead_distance=1.0, num_lin_vel=10, num_ang_vel=10, device=torch.device("cpu"))
     path = torch.stack([torch.linspace(8, 24, 30), torch.linspace(8, 24, 30) + 2 * torch.sin(torch.linspace(0, 3.14, 30))], dim=1)
     solver.update_reference_path(path)
+    used = []
+    real_select = solver._select_sub_goal
+
+    def recording_select(state_arg):
+        out = real_select(state_arg)
+        used.append((state_arg.clone(), out.clone()))
+        return out
+    solver._select_sub_goal = recording_select
+    # states next to the thresholds, inside the distance one aliased step covers (candidate 0 = the window's lowest v and
+    # omega: a few millimetres, a few tenths of a degree): 1 m + 3 mm / - 1 mm from path point 5 heading at it; bearing to
+    # path point 9 at -(90 - 0.2) and -(90 + 0.2) degrees (candidate 0 turns right, so the bearing grows)
+    p5, p9 = path[5], path[9]
+    b9 = math.atan2(float(p9[1]) - 12.5, float(p9[0]) - 12.0)
+    extra = [torch.tensor([float(p5[0]) - 1.003, float(p5[1]), 0.0]), torch.tensor([float(p5[0]) - 0.999, float(p5[1]), 0.0]),
+             torch.tensor([12.0, 12.5, b9 - math.radians(89.8)]), torch.tensor([12.0, 12.5, b9 + math.radians(90.2)]),
+             torch.tensor([12.0, 12.5, b9 - math.radians(90.2)]),
+             torch.tensor([23.6, 25.9, 2.5])]                                                      # nothing ahead: the path's end
+    n_solves = 3 + len(extra)
     out = dict(R=dyn._traversability_model._risks.numpy(), G=G, res=res, T=T, thr=0.3, goal=goal.numpy(), path=path.numpy(),
-               a_lim=np.array([0.5, 1.0], np.float32), delta_t=0.1, lookahead=1.0, nv=10, nw=10, n_solves=3,
+               a_lim=np.array([0.5, 1.0], np.float32), delta_t=0.1, lookahead=1.0, nv=10, nw=10, n_solves=n_solves,
                torch_version=torch.__version__)
     state = torch.tensor([8.0, 8.0, 0.3])
-    for i in range(3):
+    differs = 0
+    for i in range(n_solves):
+        if i >= 3:
+            state = extra[i - 3]
+        out[f"prev_action_{i}"] = solver._previous_action_seq[0].numpy().copy() if solver._previous_action_seq.dim() == 2 else np.zeros(2, np.float32)
         actions = solver._generate_actions()
-        sub_goal = solver._select_sub_goal(state)
+        naive = real_select(state)                                    # what the input state would have given
+        used.clear()
         with torch.no_grad():
             a_opt, x_opt = solver(state.clone())
-        cost = solver._compute_costs(solver._state_seq_batch, actions)
+        (sel_state, sub_goal), = used
+        differs += int(not torch.equal(naive, sub_goal))
+        cost = solver._weights.new_tensor(0)                           # costs: recompute with the sub-goal the forward used
+        sb = solver._state_seq_batch
+        cost = torch.zeros(sb.shape[0])
+        for t in range(T):
+            cost += solver._stage_cost(sb[:, t, :], actions, sub_goal)
+        cost += solver._terminal_cost(sb[:, -1, :])
+        assert torch.allclose(torch.softmax(-cost, dim=0), solver._weights, rtol=0, atol=1e-7)
         out[f"state_{i}"] = state.numpy().copy(); out[f"actions_{i}"] = actions.numpy().copy()
-        out[f"sub_goal_{i}"] = sub_goal.numpy().copy(); out[f"a_opt_{i}"] = a_opt.numpy().copy()
+        out[f"sub_goal_{i}"] = sub_goal.numpy().copy(); out[f"sub_goal_state_{i}"] = sel_state.numpy().copy()
+        out[f"sub_goal_naive_{i}"] = naive.numpy().copy()
+        out[f"a_opt_{i}"] = a_opt.numpy().copy()
         out[f"x_opt_{i}"] = x_opt[0].numpy().copy(); out[f"cost_{i}"] = cost.numpy().copy()
         out[f"w_{i}"] = solver._weights.numpy().copy(); out[f"X_{i}"] = solver._state_seq_batch.numpy().copy()
         state = x_opt[0, 3].clone()
         state[2] = (state[2] + math.pi) % (2 * math.pi) - math.pi
     p_ = os.path.join(HERE, "dwa.npz")
     np.savez_compressed(p_, **out)
-    print(f"dwa            G={G} T={T} candidates=100 solves=3 -> {os.path.getsize(p_)/1024:.0f} KiB")
+    print(f"dwa            G={G} T={T} candidates=100 solves={n_solves}, sub-goal differs from the input state's pick in {differs} -> {os.path.getsize(p_)/1024:.0f} KiB")
 
 
 def run_sampled_case():
@@ -251,10 +296,183 @@ def run_sampled_case():
     print(f"sampled        G={G} K={K} T={T} max_w={float(w.max()):.3f} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+class _CaptureNormal:
+    """Records every torch.normal draw (what Normal.sample() calls) as its standard normal z by replaying the generator
+    state; checks z * scale + loc == the sample bit for bit."""
+
+    def __init__(self):
+        self.drawn, self._real = [], torch.normal
+
+    def __enter__(self):
+        def capturing(loc, scale, *a, **k):
+            st = torch.get_rng_state()
+            sample = self._real(loc, scale, *a, **k)
+            after = torch.get_rng_state()
+            torch.set_rng_state(st)
+            z = torch.empty_like(sample).normal_()
+            assert torch.equal(torch.get_rng_state(), after) and torch.equal(z * scale + loc, sample), "draw replay drifted"
+            self.drawn.append(z.reshape(-1).clone())
+            return sample
+        torch.normal = capturing
+        return self
+
+    def __exit__(self, *exc):
+        torch.normal = self._real
+
+    def take(self):
+        out, self.drawn = self.drawn, []
+        return out
+
+
+def _env_grid_map(G, res, mean_map, std_map):
+    tens = {"heights": torch.zeros(G, G), "slopes": torch.zeros(G, G), "t_classes": torch.zeros(G, G), "colors": torch.zeros(3, G, G)}
+    dist = {"latent_models": Normal(mean_map, std_map), "predictions": Normal(mean_map, std_map)}
+    return GridMap(grid_size=G, resolution=res, tensors=tens, distributions=dist, instance_name="synthetic", device="cpu")
+
+
+def run_env_case():
+    """The REAL PlanetaryEnv (planetary_env.py:27-232): reset, >= 200 steps with every slip draw captured, the goal
+    reached on the way and stepped past (the reference does not freeze a terminated environment), and a collision_check
+    batch.  Pins oracle_env_step / oracle_collision_check (CPU) and bn_mppi_env_step / bn_mppi_env_collision_check (GPU)."""
+    from src.simulator.planetary_env import PlanetaryEnv
+    G, res = 64, 0.5
+    mean_map = smooth_risk_map(G, 11) * 0.6
+    std_map = slip_std_map(G, 11)
+    gm = _env_grid_map(G, res, mean_map, std_map)
+    start, goal = torch.tensor([6.3, 7.1]), torch.tensor([11.0, 12.5])
+    with _CaptureNormal() as cap:
+        env = PlanetaryEnv(grid_map=gm, start_pos=start, goal_pos=goal, seed=5, delta_t=0.1, time_limit=23.0, stuck_threshold=0.1,
+                           goal_threshold=1.0, device="cpu")
+        state = env.reset(seed=3)
+        cap.take()                                                      # the constructor's and reset's own collision checks
+        s0 = state.clone()
+        g = torch.Generator().manual_seed(17)
+        n = 260
+        states, actions, zs, rewards, term, trunc = [s0.numpy().copy()], [], [], [], [], []
+        for i in range(n):
+            d = goal - state[:2]
+            err = torch.atan2(d[1], d[0]) - state[2]
+            err = (err + math.pi) % (2 * math.pi) - math.pi
+            # a crude steering law plus noise; some commands lie outside the action bounds (transit re-clamps, robot_model.py:82-83)
+            a = torch.stack([0.3 + 1.1 * torch.rand((), generator=g), 2.0 * err + 0.8 * torch.randn((), generator=g)]).float()
+            state, reward, is_term, is_trunc = env.step(a)
+            (z,) = cap.take()
+            assert z.numel() == 1
+            states.append(state.numpy().copy()); actions.append(a.numpy().copy()); zs.append(float(z))
+            rewards.append(float(reward)); term.append(bool(is_term)); trunc.append(bool(is_trunc))
+        assert any(term) and not term[0] and sum(term) > 5, "the episode must reach the goal and keep stepping"
+        first = term.index(True)
+        assert not np.array_equal(states[first + 1], states[first + 3]), "reference environment moved on after terminating"
+        # collision_check: (B, N, 3) positions, some outside the map (index clamp, grid_map.py:209)
+        B, N = 3, 9
+        pos = torch.cat([torch.rand(B, N, 2, generator=g) * 40.0 - 4.0, torch.zeros(B, N, 1)], 2)
+        cc = env.collision_check(pos)
+        (zc,) = cap.take()
+        env.stuck_threshold = 0.55                                      # a threshold that splits the batch
+        cc2 = env.collision_check(pos)
+        (zc2,) = cap.take()
+    out = dict(G=G, res=res, MU=mean_map.numpy(), SG=std_map.numpy(), start=start.numpy(), goal=goal.numpy(), delta_t=0.1, time_limit=23.0,
+               stuck_threshold=0.1, goal_threshold=1.0, x_limits=np.asarray(gm.x_limits, np.float64), y_limits=np.asarray(gm.y_limits, np.float64),
+               states=np.asarray(states, np.float32), actions=np.asarray(actions, np.float32), z=np.asarray(zs, np.float32),
+               rewards=np.asarray(rewards, np.float32), terminated=np.asarray(term), truncated=np.asarray(trunc),
+               cc_states=pos.numpy(), cc_z=zc.reshape(B, N).numpy(), cc_out=cc.numpy(), cc2_z=zc2.reshape(B, N).numpy(), cc2_out=cc2.numpy(),
+               cc2_threshold=0.55, torch_version=torch.__version__)
+    path = os.path.join(HERE, "env.npz")
+    np.savez_compressed(path, **out)
+    print(f"env            G={G} steps={n} goal reached at step {first}, {sum(term)} terminated steps, truncated {sum(trunc)}, "
+          f"collisions {int(cc.sum())}/{cc.numel()} and {int(cc2.sum())}/{cc2.numel()} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
+def _episode_problem(G=64, res=0.5):
+    mean_map = smooth_risk_map(G, 21) * 0.75
+    std_map = slip_std_map(G, 21)
+    return mean_map, std_map, torch.tensor([8.0, 8.0]), torch.tensor([14.0, 15.0])
+
+
+def run_episode_case():
+    """Free-running closed loop of the reference (test_mppi.py:171-198: solver.forward -> env.step -> env.collision_check,
+    until terminated or truncated) with the REAL MPPI and the REAL PlanetaryEnv: (a) 32 seeds, outcomes only (goal reached,
+    steps, final distance, mean reward) for the statistical check of SURVEY 8a (vi); (b) one small episode with every
+    noise block and slip draw stored, for a like-for-like free-running replay."""
+    from src.simulator.planetary_env import PlanetaryEnv
+    G, res, thr = 64, 0.5, 0.3
+    mean_map, std_map, start, goal = _episode_problem(G, res)
+    gm = _env_grid_map(G, res, mean_map, std_map)
+
+    def make(seed, K, T, time_limit, start=start):
+        env = PlanetaryEnv(grid_map=gm, start_pos=start, goal_pos=goal, seed=seed, delta_t=0.1, time_limit=time_limit, stuck_threshold=thr,
+                           device="cpu")
+        dyn = UnicycleModel(grid_map=gm, model_config=ModelConfig(mode="inference", inference_metric="expected_value"), device="cpu")
+        obj = Objectives(dyn, goal_pos=env._goal_pos, stuck_threshold=env.stuck_threshold)
+        solver = MPPI(horizon=T, num_samples=K, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, sigmas=torch.tensor([0.5, 0.5]),
+                      lambda_=0.5, device=torch.device("cpu"), seed=seed)
+        return env, dyn, solver
+
+    import matplotlib.pyplot as plt
+    K, T, limit = 256, 20, 40.0
+    n_seeds = 32
+    reached, steps, final_dist, mean_reward = [], [], [], []
+    for seed in range(n_seeds):
+        env, dyn, solver = make(seed, K, T, limit)
+        state = env.reset(seed=seed)
+        plt.close("all")
+        rs = []
+        for i in range(int(limit / 0.1)):
+            with torch.no_grad():
+                action_seq, state_seq = solver.forward(state=state)
+            state, reward, is_term, is_trunc = env.step(action_seq[0, :])
+            env.collision_check(states=state_seq)
+            rs.append(float(reward))
+            if is_term or is_trunc:
+                break
+        reached.append(bool(is_term)); steps.append(i + 1)
+        final_dist.append(float(torch.norm(state[:2] - goal))); mean_reward.append(float(np.mean(rs)))
+    R = dyn._traversability_model._risks.clone()
+    # (b) one small episode, everything that was drawn stored: eps of every solve, the slip draw of every env.step
+    Ks, Ts = 64, 12
+    env, dyn, solver = make(100, Ks, Ts, limit, start=torch.tensor([10.0, 10.5]))      # nearer start: the stored episode must arrive
+    with _CaptureNormal() as cap:
+        state = env.reset(seed=100)
+        plt.close("all")
+        cap.take()
+        ep_states, ep_eps, ep_z, ep_act, ep_term = [state.numpy().copy()], [], [], [], []
+        for i in range(220):
+            with torch.no_grad():
+                action_seq, state_seq = solver.forward(state=state)
+            ep_eps.append((solver._action_noises / torch.tensor([0.5, 0.5])).numpy().copy())
+            state, reward, is_term, is_trunc = env.step(action_seq[0, :])
+            (z,) = cap.take()
+            env.collision_check(states=state_seq)
+            cap.take()
+            ep_states.append(state.numpy().copy()); ep_z.append(float(z)); ep_act.append(action_seq[0].numpy().copy()); ep_term.append(bool(is_term))
+            if is_term or is_trunc:
+                break
+    out = dict(G=G, res=res, thr=thr, R=R.numpy(), MU=mean_map.numpy(), SG=std_map.numpy(), start=start.numpy(), goal=goal.numpy(),
+               K=K, T=T, time_limit=limit, goal_threshold=1.0, delta_t=0.1, n_seeds=n_seeds,
+               reached=np.asarray(reached), steps=np.asarray(steps, np.int32), final_dist=np.asarray(final_dist, np.float32),
+               mean_reward=np.asarray(mean_reward, np.float32),
+               ep_K=Ks, ep_T=Ts, ep_seed=100, ep_states=np.asarray(ep_states, np.float32), ep_eps=np.asarray(ep_eps, np.float32),
+               ep_z=np.asarray(ep_z, np.float32), ep_actions=np.asarray(ep_act, np.float32), ep_terminated=np.asarray(ep_term),
+               torch_version=torch.__version__)
+    path = os.path.join(HERE, "episodes.npz")
+    np.savez_compressed(path, **out)
+    print(f"episodes       {n_seeds} seeds K={K} T={T}: reached {sum(reached)}/{n_seeds}, steps median {int(np.median(steps))} "
+          f"[{min(steps)}, {max(steps)}], final distance mean {np.mean(final_dist):.2f}; replay episode {len(ep_z)} steps "
+          f"(terminated {ep_term[-1]}) -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     pi = math.pi
     if sys.argv[1:] == ["sampled"]:
         return run_sampled_case()
+    if sys.argv[1:] == ["dwa"]:
+        return run_dwa_case()
+    if sys.argv[1:] == ["env"]:
+        return run_env_case()
+    if sys.argv[1:] == ["episodes"]:
+        return run_episode_case()
+    run_env_case()
+    run_episode_case()
     run_riskmap_case()
     run_sampled_case()
     run_dwa_case()

@@ -32,6 +32,42 @@ def test_oracle_dwa_matches_reference_fixture():
         assert np.abs(got["X"][got["best"]] - fx[f"x_opt_{i}"]).max() <= 1e-4
 
 
+def test_sub_goal_is_picked_from_candidate_zeros_aliased_slot():
+    """the reference's sub-goal rule runs on state_seq_batch[0, 0, :] after the rollouts (dwa.py:240-244), i.e. on
+    the input state advanced by candidate 0's first un-clamped step.  The fixture holds threshold-adjacent states where
+    that changes the pick (sub_goal_naive = what the input state itself would give)."""
+    fx = _fx()
+    p = _params(fx)
+    changed = 0
+    for i in range(int(fx["n_solves"])):
+        sg, sel, idx = O.dwa_sub_goal(p, fx["R"], fx[f"state_{i}"], fx[f"actions_{i}"][0], fx["path"], float(fx["lookahead"]))
+        assert np.abs(sel - fx[f"sub_goal_state_{i}"]).max() <= 1e-6
+        assert np.array_equal(sg, fx[f"sub_goal_{i}"]), i
+        changed += int(not np.array_equal(fx[f"sub_goal_{i}"], fx[f"sub_goal_naive_{i}"]))
+    assert changed >= 2
+
+
+def test_drop_in_class_sub_goal_state_on_the_host():
+    """benchnav_amd.DWA's host-side restatement of that slot-0 state and the rule on it (no GPU needed for this part)."""
+    import torch
+    from benchnav_amd.dwa import DWA
+    fx = _fx()
+    d = DWA.__new__(DWA)
+    torch.nn.Module.__init__(d)
+    d._dtype = torch.float32
+    d._risk_cpu = torch.tensor(fx["R"])
+    G, res = int(fx["G"]), float(fx["res"])
+    d._grid = (G, res, (0.0, G * res), (0.0, G * res))
+    d._u_min, d._u_max = torch.tensor([0.0, -1.0]), torch.tensor([1.0, 1.0])
+    d._lookahead_distance = float(fx["lookahead"])
+    d.reference_path = torch.tensor(fx["path"])
+    same_build = str(fx["torch_version"]) == torch.__version__
+    for i in range(int(fx["n_solves"])):
+        sel = d._sub_goal_state(torch.tensor(fx[f"state_{i}"]), torch.tensor(fx[f"actions_{i}"][0]))
+        assert np.abs(sel.numpy() - fx[f"sub_goal_state_{i}"]).max() <= (0 if same_build else 1e-6)
+        assert np.array_equal(d._select_sub_goal(sel).numpy(), fx[f"sub_goal_{i}"]), i
+
+
 @pytest.mark.gpu
 def test_kernel_matches_oracle_and_reference():
     from benchnav_amd import NativeMPPI
@@ -76,7 +112,7 @@ def test_drop_in_class_follows_the_reference_run():
             solver._previous_action_seq = torch.tensor(fx[f"a_opt_{i - 1}"], device="cuda")
         acts = solver._generate_actions()
         assert np.abs(acts.numpy() - fx[f"actions_{i}"]).max() <= (0 if same_build else 1e-6)
-        assert np.array_equal(solver._select_sub_goal(state).numpy(), fx[f"sub_goal_{i}"])
+        assert np.array_equal(solver._select_sub_goal(solver._sub_goal_state(state, acts[0])).numpy(), fx[f"sub_goal_{i}"])
         a_opt, x_opt = solver(state)
         assert a_opt.shape == (1, 2) and x_opt.shape == (1, int(fx["T"]) + 1, 3) and a_opt.is_cuda
         assert np.abs(a_opt.cpu().numpy() - fx[f"a_opt_{i}"]).max() <= 1e-6

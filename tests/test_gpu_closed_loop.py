@@ -91,18 +91,22 @@ def test_pipelined_episode_equals_host_driven_loop_bitwise():
     assert np.isfinite(full[0]).all() and (np.abs(np.diff(full[0][:, :, :2], axis=0)) <= 0.1 + 1e-6).all()
 
 
-def test_goal_arrival_freezes_the_instance():
+@pytest.mark.parametrize("freeze", [True, False], ids=["freeze-opt-in", "reference-default"])
+def test_goal_arrival(freeze):
     fx = load_case("c1_basic")
     G = int(fx["G"])
     lat_mean, lat_std = np.zeros((G, G), np.float32), np.zeros((G, G), np.float32)     # slip 0: full traversability
     start = np.array([float(fx["goal"][0]) - 1.3, float(fx["goal"][1]), 0.0], np.float32)   # 1.3 m from the goal, heading to it
     with native_planner_for(fx) as pl:
         pl.set_map(np.zeros((G, G), np.float32)); pl.set_goal(fx["goal"])
-        pl.env_attach(lat_mean, lat_std, goal_threshold=1.0)
+        pl.env_attach(lat_mean, lat_std, goal_threshold=1.0, freeze_on_goal=freeze)
         states, rewards, done = pl.episode(30, start)
     d = np.linalg.norm(states[:, 0, :2] - fx["goal"][None], axis=1)
     assert done[0] >= 0, "the rover should reach the 1 m goal disc within 30 steps"
     k = done[0]
     assert d[k + 1] < 1.0 <= d[k]                                  # first state inside the disc is the one after step k
-    assert np.array_equal(states[k + 1:], np.repeat(states[k + 1:k + 2], len(states) - k - 1, axis=0))   # frozen afterwards
+    if freeze:      # opt-in: an instance inside the goal disc stays put
+        assert np.array_equal(states[k + 1:], np.repeat(states[k + 1:k + 2], len(states) - k - 1, axis=0))
+    else:           # the reference's PlanetaryEnv keeps moving when a terminated episode is stepped (planetary_env.py:189-219)
+        assert not np.array_equal(states[k + 1], states[k + 3])
     assert (rewards == 1.0).all()

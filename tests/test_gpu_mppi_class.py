@@ -103,3 +103,45 @@ def test_sampled_slip_opt_in_plans_with_observation_mode_dynamics():
     assert np.array_equal(U.cpu().numpy(), us[0]) and np.array_equal(X[0].cpu().numpy(), xs[0])
     with pytest.raises(TypeError):                       # inference-mode dynamics cannot be sampled
         MPPI(T, K, 3, 2, FakeDynamics(mu, gm), obj, torch.tensor([0.5, 0.5]), 0.5, sampled_slip=True)
+
+
+def test_lean_class_serves_top_samples_and_state_batch_by_rerolling():
+    """lean=True: no trajectory batch in HBM; get_top_samples re-rolls the winners, `_state_seq_batch` all K rows, both
+    bit-identical to the full-API planner on the same (Philox) noise."""
+    import torch
+    from helpers import load_case, mppi_for_fixture
+    fx = load_case("c2")
+    state = torch.tensor(fx["state_0"], device="cuda")
+    res = {}
+    for lean in (False, True):
+        solver = mppi_for_fixture(fx, noise="philox", store_controls=False, lean=lean)
+        for _ in range(3):
+            U, X = solver(state)
+        top_s, top_w = solver.get_top_samples(64)
+        res[lean] = (U.cpu().numpy(), X.cpu().numpy(), top_s.cpu().numpy(), top_w.cpu().numpy(), solver._state_seq_batch.cpu().numpy(),
+                     solver._weights.cpu().numpy())
+        if lean:
+            assert solver._buf_X is None
+    for a, b in zip(res[False], res[True]):
+        assert np.array_equal(a, b)
+
+
+def test_forward_under_a_different_current_stream_is_fenced():
+    """the planner enqueues on its construction-time stream; a forward() issued under another current stream
+    must still see the state written on that stream and hand back outputs ordered on it."""
+    import torch
+    from helpers import load_case, mppi_for_fixture
+    fx = load_case("c1_basic")
+    solver = mppi_for_fixture(fx, noise="philox")
+    ref = mppi_for_fixture(fx, noise="philox")
+    side = torch.cuda.Stream()
+    base = torch.tensor(fx["state_0"], device="cuda")
+    for i in range(5):
+        with torch.cuda.stream(side):
+            st = base + 0.01 * i                       # produced on the side stream right before the call
+            U, X = solver(st)
+            got = (U.clone(), X.clone())
+        side.synchronize()
+        U2, X2 = ref(base + 0.01 * i)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], U2) and torch.equal(got[1], X2), i

@@ -1,16 +1,28 @@
-"""Latency of the drop-in class used the reference way: one forward(state) per control step, outputs consumed on the host."""
+"""Latency of the drop-in class used the reference way: one forward(state) per control step, outputs consumed on the host.
+Per mode: host time of the forward() call itself (how long Python is busy before it returns), and the full step
+forward() + read-back of action_seq[0] (what the reference loop does every control step, test_mppi.py:174-181)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 from helpers import load_case, mppi_for_fixture
+torch.set_num_threads(1)
 fx = load_case("c2")
-for mode, copy in (("torch", True), ("philox", True), ("philox", False), ("torch_device", True)):
-    solver = mppi_for_fixture(fx, noise=mode, copy_outputs=copy, store_controls=False)
+for mode, copy, lean in (("torch", True, False), ("torch_device", True, False), ("philox", True, False), ("philox", False, False), ("philox", False, True)):
+    solver = mppi_for_fixture(fx, noise=mode, copy_outputs=copy, store_controls=False, lean=lean)
     state = torch.tensor(fx["state_0"], device="cuda")
-    for _ in range(20): U, X = solver(state)
-    torch.cuda.synchronize(); t = time.perf_counter(); n = 300
+    for _ in range(50): U, X = solver(state)
+    torch.cuda.synchronize(); n = 500
+    host = 0.0
+    t = time.perf_counter()
     for _ in range(n):
+        t0 = time.perf_counter()
         U, X = solver(state)
+        host += time.perf_counter() - t0
         a = U[0].cpu()                      # the reference loop reads action_seq[0] every step
     dt = (time.perf_counter() - t) / n
-    print(f"noise={mode:12s} copy_outputs={copy}: {dt*1e6:7.1f} us per forward()+readback  ({1/dt:.0f} Hz)")
+    # back-to-back forwards without a read-back: the rate the host can feed the GPU at
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): U, X = solver(state)
+    torch.cuda.synchronize(); dq = (time.perf_counter() - t) / n
+    print(f"noise={mode:12s} copy_outputs={copy!s:5s} lean={lean!s:5s}: forward() host {host / n * 1e6:6.1f} us | forward()+readback {dt * 1e6:6.1f} us "
+          f"({1 / dt:.0f} Hz) | back-to-back {dq * 1e6:6.1f} us", flush=True)
