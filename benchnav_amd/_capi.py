@@ -56,7 +56,7 @@ SYMBOLS = {
     "bn_mppi_get_mean": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_solve": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, _FP, _FP]),
     "bn_mppi_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
-    "bn_mppi_forward_async": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int]),
+    "bn_mppi_forward_async": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bn_mppi_solve_n_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64]),
     "bn_mppi_set_rollout_offset": (C.c_int, [_H, C.c_int64]),
     "bn_mppi_shard_rollout_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),

@@ -36,9 +36,11 @@ int fail(int code, const char *fmt, ...)
 #define BN_HIP(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
+        if (e_ != hipSuccess) {                                                              \
+            (void)hipGetLastError();   /* reported here: do not leave it for the next HIP user of the process (torch) */ \
             return fail(BN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
                         __FILE__, __LINE__);                                                 \
+        }                                                                                    \
     } while (0)
 
 bool is_pow2_float(float v)
@@ -151,10 +153,11 @@ int ensure_scratch(bn_mppi *h, size_t bytes)
 }
 
 // Write the tail (U*, next mean, X*, weights, cost copy) of the latest solve if it is still pending.
-int flush_tail(bn_mppi *h)
+int flush_tail(bn_mppi *h, float *out_copy = nullptr)
 {
     if (!h->tail_pending) return BN_OK;
     bn::SolveParams p = h->p;
+    p.out_copy = out_copy;
     const int cur = (int)((h->solves - 1) & 1);
     p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
     if (h->ticket_mode) {
@@ -298,7 +301,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         if (rc != BN_OK) return;
         hipError_t e = hipMalloc((void **)ptr, bytes);
         if (e == hipSuccess) e = hipMemset(*ptr, 0, bytes);
-        if (e != hipSuccess) rc = fail(BN_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();       // reported through rc: the sticky error must not surface in the caller's next torch call
+            rc = fail(BN_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
     };
     const size_t B = p.B, K = p.K, T = p.T, G = p.G;
     alloc(&h->d_map, (size_t)h->n_maps * G * G * 4);
@@ -626,13 +632,18 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     return solve_impl(h, states, states_where, eps, noise, false);
 }
 
-int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise)
+int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise, float *out_device)
 {
     // MPPI.forward as ONE call for a host loop that consumes every solve's outputs (test_mppi.py:174-183): the solve and
     // its tail, both only enqueued; U*, X*, weights are in the device buffers in stream order.
     if (int rc = solve_impl(h, states_device, BN_MEM_DEVICE, eps_device, noise, false)) return rc;
     BN_BIND(h);
-    return flush_tail(h);
+    if (!h->tail_pending && out_device) {              // two-launch modes: the tail has run; one small copy on the stream
+        const size_t n = (size_t)h->p.B * ((size_t)h->p.T * 2 + ((size_t)h->p.T + 1) * 3);
+        BN_HIP(hipMemcpyAsync(out_device, h->d_ustar, n * 4, hipMemcpyDeviceToDevice, h->stream));
+        return BN_OK;
+    }
+    return flush_tail(h, out_device);
 }
 
 int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout)

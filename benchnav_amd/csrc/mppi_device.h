@@ -463,7 +463,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 
 // The tail of one solve of instance b: U* (and the next mean), softmin statistics, normalised weights,
 // a stable copy of the costs, and the batch-1 rollout X* of U*.  NT threads (320 as the aux workgroup, 1024 stand-alone for large K).
-// LDS: [ window | ustar 2T | scale nblk | red 32 | group rows ceil(nblk/16) x (2+2T) if nblk > 64 | sampled mode: draws, (mean, std) window ]
+// LDS: [ window | ustar 2T | X* 3(T+1) | scale nblk | red 32 | group rows ceil(nblk/16) x (2+2T) if nblk > 64 | sampled mode: draws, (mean, std) window ]
 template <int GEO, bool LDSWIN, int NT, bool BIG = false>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
@@ -473,7 +473,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     const int T = p.T, K = p.K, nblk = p.nblk, PS = 2 + 2 * p.T;
     float *win = smem;
     float *us = win + (LDSWIN ? p.WN * p.WN : 0);
-    float *sc = us + 2 * T;
+    float *xl = us + 2 * T;                             // X* rows: the serial rollout's lane stages them here
+    float *sc = xl + 3 * (T + 1);
     float *red = sc + nblk;
 
     const int tid = threadIdx.x;
@@ -499,6 +500,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             const float u = p.ustar_prev[(size_t)b * 2 * T + j];
             us[j] = u;
             p.ustar[(size_t)b * 2 * T + j] = u;
+            if (p.out_copy) p.out_copy[(size_t)b * 2 * T + j] = u;
         }
         m = p.stats_prev[b * 2 + 0];
         S = p.stats_prev[b * 2 + 1];
@@ -507,6 +509,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, pre_ok ? &pre : nullptr);
         for (int j = tid; j < 2 * T; j += NT) {
             p.ustar[(size_t)b * 2 * T + j] = us[j];
+            if (p.out_copy) p.out_copy[(size_t)b * 2 * T + j] = us[j];
             if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = p.mean[(size_t)b * 2 * T + j];   // what this solve sampled around
             p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
         }
@@ -555,7 +558,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         __syncthreads();
         BN_STAMP(12);
         if (tid == 0) {
-            float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
+            float *Xs = xl;                              // staged in LDS, written out coalesced below
             float xn, yn, tn;
             if (LDSWIN) {
                 SlipChain c;
@@ -605,7 +608,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         c.x = sx; c.y = sy; c.th = sth;
         sincos_spec(c.th, c.sn, c.cs);
         c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
-        float *Xs = p.xstar + (size_t)b * (T + 1) * 3;
+        float *Xs = xl;                              // staged in LDS, written out coalesced below
         float xn, yn, tn;
         chain_step<GEO, LDSWIN, true>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
         Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
@@ -645,6 +648,17 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             const float ck = cost[k];
             cout[k] = ck;
             wout[k] = expf((-ck) / p.lambda_ - m) / S;
+        }
+    }
+    // optimal_state_seq out of LDS: coalesced, and to the caller's copy of the packed U* | X* block as well
+    __syncthreads();
+    {
+        float *Xg = p.xstar + (size_t)b * (T + 1) * 3;
+        float *Xc = p.out_copy ? p.out_copy + (size_t)p.B * 2 * T + (size_t)b * (T + 1) * 3 : nullptr;
+        for (int i = tid; i < 3 * (T + 1); i += NT) {
+            const float v = xl[i];
+            Xg[i] = v;
+            if (Xc) Xc[i] = v;
         }
     }
 }

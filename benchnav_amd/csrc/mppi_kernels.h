@@ -87,6 +87,8 @@ struct SolveParams {
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)
+    float *out_copy;     // optional caller-owned copy of the packed (B,T,2) U* | (B,T+1,3) X* block, written by the same tail
+                         // (bn_mppi_forward_async: the drop-in class's fresh output tensors without a second launch)
     float *stats;        // (B, 2): max z, sum exp
     unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0
 };

@@ -303,7 +303,7 @@ size_t finish_lds_bytes(const SolveParams &p)
 {
     const size_t slip = p.slip_on ? 2 * (size_t)p.WN * p.WN + (size_t)p.T + 16 : 0;    // (mean, std) window + the draws of X*
     const size_t groups = (p.nblk > 64 && p.nblk <= 64 * 16) ? (size_t)((p.nblk + 15) / 16) * (2 + 2 * (size_t)p.T) : 0;   // two-level merge rows
-    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + (size_t)p.nblk + 32 + groups + slip);
+    return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + 3 * ((size_t)p.T + 1) + (size_t)p.nblk + 32 + groups + slip);
 }
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)

@@ -176,6 +176,7 @@ class MPPI(nn.Module):
         self._buf_out = self._wrap(_capi.BN_BUF_USTAR_XSTAR, (T * 2 + (T + 1) * 3,))     # U* | X*, one block
         self._buf_ustar = self._buf_out[:T * 2].view(T, 2)
         self._buf_xstar = self._buf_out[T * 2:].view(1, T + 1, 3)
+        self._n_out = T * 2 + (T + 1) * 3
         self._fwd = lib.bn_mppi_forward_async                   # bound once: forward() is a host hot loop
         self._h = self._handle.value
 
@@ -305,17 +306,19 @@ class MPPI(nn.Module):
         cs = self._cs
         cs.eps, cs.noise_cache, cs.rolled = eps, None, None           # _action_noises and lean rows are derived on demand
         cs.state = state                                               # keep alive until the kernels ran
+        # fresh output tensors like the reference's: the tail writes its packed U* | X* block into `out` as well (no extra launch)
+        out = torch.empty(self._n_out, device=self._device, dtype=self._dtype) if self._copy_outputs else None
+        optr = None if out is None else out.data_ptr()
         if torch.cuda.current_stream(self._device).cuda_stream == self._stream.cuda_stream:
-            rc = self._fwd(self._h, state.data_ptr(), eptr, kind)      # solve + tail: U*, X*, weights of THIS solve, stream-ordered
+            rc = self._fwd(self._h, state.data_ptr(), eptr, kind, optr)   # solve + tail: U*, X*, weights of THIS solve, stream-ordered
         else:
             with self._on_planner_stream():
-                rc = self._fwd(self._h, state.data_ptr(), eptr, kind)
+                rc = self._fwd(self._h, state.data_ptr(), eptr, kind, optr)
         if rc:
             _capi.check(rc)
-        if self._copy_outputs:
+        if out is not None:
             T = self._horizon
-            out = self._buf_out.clone()                                # one device copy for both outputs
-            return out[:T * 2].view(T, 2), out[T * 2:].view(1, T + 1, 3)
+            return out.as_strided((T, 2), (2, 1), 0), out.as_strided((1, T + 1, 3), (3 * (T + 1), 3, 1), 2 * T)
         return self._buf_ustar, self._buf_xstar
 
     solve = forward
@@ -337,7 +340,7 @@ class MPPI(nn.Module):
         cs.eps = eps.detach().to(self._device, self._dtype).contiguous()
         cs.noise_cache, cs.rolled, cs.state = None, None, st
         with self._on_planner_stream():
-            _capi.check(self._fwd(self._h, st.data_ptr(), cs.eps.data_ptr(), _capi.BN_NOISE_DEVICE_KT2))
+            _capi.check(self._fwd(self._h, st.data_ptr(), cs.eps.data_ptr(), _capi.BN_NOISE_DEVICE_KT2, None))
         return self._buf_ustar.clone(), self._buf_xstar.clone()
 
     def get_top_samples(self, num_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:

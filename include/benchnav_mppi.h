@@ -167,8 +167,11 @@ int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, c
 int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where,
                         const float *eps, bn_noise_kind noise);
 /* MPPI.forward (mppi.py:130-219) for a host loop that consumes every solve (test_mppi.py:174-183): bn_mppi_solve_async +
- * bn_mppi_flush in one call.  states_device (B,3) and eps_device are device pointers; nothing is copied, nothing waits. */
-int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise);
+ * bn_mppi_flush in one call.  states_device (B,3) and eps_device are device pointers; nothing waits.  out_device (may be
+ * NULL): a caller-owned device block laid out like BN_BUF_USTAR_XSTAR that the tail fills as well -- the fresh
+ * (optimal_action_seq, optimal_state_seq) tensors the reference returns, without another launch. */
+int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise,
+                          float *out_device);
 /* n dependent solves enqueued from one call (the warm start chains them on the device; the state is
  * re-read from `states` by every solve, so a device-resident state may be advanced in between by
  * other work on the same stream).  Noise block i is eps + (i % eps_ring) * eps_stride floats. */
