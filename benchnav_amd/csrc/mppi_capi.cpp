@@ -80,6 +80,7 @@ struct bn_mppi {
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
     size_t resident_wgs = 1024;      // role-kernel workgroups the device holds at once (LDS- and wave-limited) x CUs
+    bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
     bool ticket_mode = false;        // one launch per solve: ticket merge by the last workgroup + the previous tail as aux
@@ -351,6 +352,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 32 && !p.slip_on;
     // throughput kernel: launches with more workgroups than the role kernel keeps resident in one round (4 per CU)
     h->wave_kernel = h->pipelined && want_wave;
+    // latency variant: every workgroup (rollouts + aux) alone on a CU, its LDS layout must fit, not forced elsewhere
+    h->lat_kernel = h->pipelined && !h->wave_kernel && !(cfg->flags & BN_FLAG_ROLE_KERNEL) && bn::lat_lds_bytes(p) > 0 &&
+                    ((cfg->flags & BN_FLAG_LAT_KERNEL) || (size_t)p.B * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
+    if (const char *e = std::getenv("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
     // (late allocations also go through `alloc`: a failure anywhere destroys the handle and everything it owns)
     if (p.slip_on) {
         alloc(&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4);
@@ -578,6 +583,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             h->ep_len += 1;
         }
         p.wave_kernel = (h->wave_kernel && !h->in_episode) ? 1 : 0;
+        p.lat_kernel = (h->lat_kernel && !h->in_episode) ? 1 : 0;      // device-side episodes advance the state in the role kernel's prologue
         // more workgroups than the role kernel keeps resident at once (4 per CU x 256 CUs): the aux workgroups run in freed slots
         p.aux_prio = (!p.wave_kernel && (size_t)p.B * (p.nblk + 1) > h->resident_wgs) ? 1 : 0;
         if (!p.wave_kernel && !p.store_u) p.U = nullptr;          // the buffer exists for the throughput kernel only

@@ -285,20 +285,33 @@ __device__ __forceinline__ void slip_chain_step(const SolveParams &p, const floa
     c.e = slip_cell_window<GEO>(p, w, c.x, c.y);
 }
 
-// Wave-wide butterfly reductions (ds_bpermute).  A DPP row-scan formulation was measured 0.25 us faster
-// per launch but hipcc's DPP combiner mis-folds the update_dpp + add pairs inside this kernel (wrong sums
-// on hardware, correct in an isolated test kernel), so the shuffle form stays.
+// Wave-wide reductions with DPP row shifts / row broadcasts: six VALU instructions instead of six ds_bpermute round trips
+// through the LDS crossbar (~70 cycles each for a lone wave).  Written as inline assembly on purpose: expressed with
+// __builtin_amdgcn_update_dpp, hipcc's DPP combiner mis-folded the update_dpp + add pairs inside the rollout kernel (wrong
+// sums on hardware, correct in an isolated kernel).  The assembler adds no hazard padding inside an asm block, so the
+// two wait states a DPP read needs after the VALU write of its source are spelled out (s_nop 1).
+// Lanes whose DPP source does not exist are disabled (no bound_ctrl) and keep their accumulator.  After the six steps
+// lane 63 holds the reduction of all 64 lanes; v_readlane hands it to everyone.  The order of the additions is fixed
+// (inclusive scan within rows of 16, then across rows): every kernel and every caller gets the same bits.
+#define BN_DPP_REDUCE(OP, v)                                                                                   \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                          \
+                 OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                          \
+                 OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                          \
+                 OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                          \
+                 OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"                       \
+                 OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"                            \
+                 : "+v"(v))
+
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    BN_DPP_REDUCE("v_max_f32_dpp", v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    BN_DPP_REDUCE("v_add_f32_dpp", v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ------------------------------------------------------------------------------

@@ -26,6 +26,7 @@ struct SolveParams {
     int pow2;            // resolution is a power of two
     int store_u;
     int wave_kernel;     // launch the one-wave-per-64-rollouts throughput variant (many workgroups per launch)
+    int lat_kernel;      // launch the barrier-free latency variant of the role kernel (every workgroup has a CU to itself)
     int k0;              // global index of this handle's rollout 0 (K-sharded solve: rank r owns rollouts [k0, k0 + K)); keys the Philox stream
     int xs;              // log2 of the instances interleaved along grid x (rollout_grid / decode_wg): 3 keeps the workgroups of
                          // one instance on one XCD (workgroup i runs on XCD i % 8), 0 is instance-per-row
@@ -108,6 +109,7 @@ inline dim3 rollout_grid(const SolveParams &p, bool aux)
 size_t rollout_lds_bytes(const SolveParams &p);
 size_t finish_lds_bytes(const SolveParams &p);
 size_t wave_lds_bytes(const SolveParams &p);
+size_t lat_lds_bytes(const SolveParams &p);       // 0 when the latency variant cannot take this configuration
 int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer for the headline rollout kernel (diagnostics)
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);

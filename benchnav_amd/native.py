@@ -61,7 +61,7 @@ class NativeMPPI:
                      | (0 if pipeline else _capi.BN_FLAG_NO_PIPELINE)
                      | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0)
                      | (_capi.BN_FLAG_LEAN if lean else 0)
-                     | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL}[kernel])
+                     | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL, "lat": _capi.BN_FLAG_LAT_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
         self.device_id, self.stream = device_id, stream       # stream: the hipStream_t the handle enqueues on (None: private)

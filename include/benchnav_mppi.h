@@ -76,6 +76,8 @@ enum {
     BN_FLAG_NO_PIPELINE = 1u << 5,     /* always two launches per solve (rollout, finish); see bn_mppi_solve_async */
     BN_FLAG_WAVE_KERNEL = 1u << 7,     /* always use the one-wave-per-64-rollouts throughput kernel (default: chosen by launch size) */
     BN_FLAG_ROLE_KERNEL = 1u << 8,     /* always use the five-wave role-split latency kernel */
+    BN_FLAG_LAT_KERNEL = 1u << 10,     /* always use the barrier-free latency variant of the role kernel when it fits (default: when the
+                                          launch leaves every workgroup a CU to itself) */
     BN_FLAG_LEAN = 1u << 9,            /* lean mode: _state_seq_batch (mppi.py:119-125) is not materialised -- 70 % of a solve's
                                           HBM bytes; bn_mppi_get_states / bn_mppi_get_top_samples / bn_mppi_reroll_async
                                           regenerate the requested rows of the latest solve bit-identically on demand */

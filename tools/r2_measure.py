@@ -12,6 +12,9 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+if os.environ.get("BN_VARIANT"):                              # a library built with other -D flags: tools/_ablate/lib_<variant>.so
+    from benchnav_amd import build as _b
+    _b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ["BN_VARIANT"])
 from benchnav_amd import NativeMPPI, synth
 
 K, T, G = int(os.environ.get("BN_K", 1024)), int(os.environ.get("BN_T", 50)), int(os.environ.get("BN_G", 256))
