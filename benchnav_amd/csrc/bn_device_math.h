@@ -35,8 +35,17 @@ __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
     pq = __builtin_elementwise_fma(pq, s2, v2f{-0.0001980613305931911f, -0.001388839678838849f});
     pq = __builtin_elementwise_fma(pq, s2, v2f{0.008333009667694569f, 0.04166664183139801f});
     pq = __builtin_elementwise_fma(pq, s2, v2f{-0.16666656732559204f, -0.5f});
-    const float S = __builtin_fmaf(pq.x * s, r, r);
-    const float C = __builtin_fmaf(pq.y, s, 1.0f);
+    // two plain FMAs, pinned: left to itself the vectoriser packs them into one v_pk_fma_f32 whose operand pairs cost two
+    // register moves and a hazard slot -- four issue slots instead of two on the one wave whose slots are the solve's latency
+    float S, C;
+#ifdef BN_VAR_NO_SINCOS_ASM
+    S = __builtin_fmaf(pq.x * s, r, r);
+    C = __builtin_fmaf(pq.y, s, 1.0f);
+#else
+    const float ps = pq.x * s;
+    asm("v_fma_f32 %0, %1, %2, %2" : "=v"(S) : "v"(ps), "v"(r));
+    asm("v_fma_f32 %0, %1, %2, 1.0" : "=v"(C) : "v"(pq.y), "v"(s));
+#endif
     const uint32_t sign = __float_as_uint(t) << 31;          // parity of n
     sn = __uint_as_float(__float_as_uint(S) ^ sign);
     cs = __uint_as_float(__float_as_uint(C) ^ sign);

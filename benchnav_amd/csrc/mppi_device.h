@@ -314,6 +314,34 @@ __device__ __forceinline__ float wave_sum(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Device-scope accesses that bypass the per-XCD L2 (sc1): what lets workgroups on different XCDs exchange their
+// partials inside one launch without a full L2 write-back / invalidate (see ticket_merge).
+__device__ __forceinline__ void store_agent(float *ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_agent(const float *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The workgroup's weighted control sums  sum_k e_k u_k[j]  (mppi.py:196-199, before the cross-workgroup merge) for the
+// 2T columns j of the LDS control tile (pitch kUPad).  One definition of the summation order for every rollout kernel,
+// so that all of them produce the same bits: the 64 rollouts in four quarters of 16, each summed in rollout order with
+// fma, combined as (q0 + q1) + (q2 + q3).  Here four adjacent lanes take the quarters of one column (2T x 4 work items
+// over NT threads; 64 sequential fma per column on a quarter of the threads was 0.55 us of a 13 us solve) and the
+// combination is two DPP quad permutes.  NT and the item count are multiples of 4: a quad is active as a whole.
+template <int NT, bool AGENT>
+__device__ __forceinline__ void column_sums(const float *Ul, const float *el, int T, int tid, float *part)
+{
+    for (int it = tid; it < 8 * T; it += NT) {
+        const int j = it >> 2, r = it & 3;
+        const float *col = Ul + j * kUPad + 16 * r, *e = el + 16 * r;
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc = __builtin_fmaf(e[q], col[q], acc);
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                     : "+v"(acc));
+        if (r == 0) { if (AGENT) store_agent(part + 2 + j, acc); else part[2 + j] = acc; }
+    }
+}
+
 // ------------------------------------------------------------------------------
 // Softmin merge and the tail of a solve (shared by the finish kernel, the aux block of the
 // pipelined rollout kernel, and the rollout blocks' own prologue merge).
@@ -329,11 +357,6 @@ __device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool
     __syncthreads();
     return r;
 }
-
-// Device-scope accesses that bypass the per-XCD L2 (sc1): what lets workgroups on different XCDs exchange their
-// partials inside one launch without a full L2 write-back / invalidate (see ticket_merge).
-__device__ __forceinline__ void store_agent(float *ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float load_agent(const float *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Merge the nblk per-block statistics (max z, sum e, sum e*u) of one instance into
 //   U*[j] = sum_k w_k u_k[j]      mppi.py:193-199
@@ -408,7 +431,7 @@ __device__ __forceinline__ void merge_group(const float *__restrict__ part, int 
 // prologue / aux / ticket merges): it costs them registers.
 template <int NT, bool AGENT = false, bool BIG = false>
 __device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
-                                               float *red, int tid, float &m_out, float &S_out, const MergeLoads *pre)
+                                               float *red, int tid, float &m_out, float &S_out, bool have_pre, const MergeLoads &pre)
 {
 #define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
     const int PS = 2 + 2 * T;
@@ -418,7 +441,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         // Few blocks (K <= 4096): every wave reduces the nblk (max, sum) pairs itself -- same inputs,
         // same operations, so all waves (and all workgroups) hold identical m, S and scales -- and all
         // loads are issued before the first use: one memory round trip, one barrier.
-        const MergeLoads L = pre ? *pre : merge_issue<AGENT>(part, nblk, T, tid);
+        const MergeLoads L = have_pre ? pre : merge_issue<AGENT>(part, nblk, T, tid);
         m = wave_max(L.mi);
         const float f = lane < nblk ? expf(L.mi - m) : 0.0f;       // scale of block `lane`; 0 past nblk
         S = wave_sum(L.si * f);
@@ -446,7 +469,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         for (int g = tid >> 6; g < ng; g += NW)
             if constexpr (BIG) merge_group<AGENT, false>(part, g * kGroupRows, min(kGroupRows, nblk - g * kGroupRows), T, lane, 0, 1, grows + (size_t)g * PS);
         __syncthreads();
-        merge_partials<NT, false, false>(grows, ng, T, us, sc, red, tid, m, S, nullptr);
+        merge_partials<NT, false, false>(grows, ng, T, us, sc, red, tid, m, S, false, MergeLoads{});
         m_out = m;
         S_out = S;
         return;
@@ -497,7 +520,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     BN_STAMP(8);
 
     // the merge's loads go out before the window staging (which waits for the state): one memory round trip for both
-    MergeLoads pre;
+    MergeLoads pre{};
     const bool pre_ok = !p.tail_merged && nblk <= 64;
     if (pre_ok) pre = merge_issue(part, nblk, T, tid);
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
@@ -519,7 +542,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         S = p.stats_prev[b * 2 + 1];
         __syncthreads();
     } else {
-        merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, pre_ok ? &pre : nullptr);
+        merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
         for (int j = tid; j < 2 * T; j += NT) {
             p.ustar[(size_t)b * 2 * T + j] = us[j];
             if (p.out_copy) p.out_copy[(size_t)b * 2 * T + j] = us[j];
@@ -720,7 +743,7 @@ __device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, int bl
     BN_STAMP_ANY(6);
     if (tid == 0) ticket[0] = 0;                       // ready for the next launch (ordered by the stream)
     float m, S;
-    merge_partials<NT, true, false>(rows, nrows, T, us, sc, red, tid, m, S, nullptr);
+    merge_partials<NT, true, false>(rows, nrows, T, us, sc, red, tid, m, S, false, MergeLoads{});
     for (int j = tid; j < 2 * T; j += NT) {
         p.ustar_cur[(size_t)b * 2 * T + j] = us[j];
         if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = p.mean[(size_t)b * 2 * T + j];   // what this solve sampled around

@@ -172,14 +172,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         }
     }
     __syncthreads();
-    float *part = p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T);
-    for (int j = tid; j < 2 * T; j += kSampledThreads) {
-        const float *col = Ul + j * kUPad;
-        float acc = 0.0f;
-#pragma unroll 16
-        for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
-        store_agent(part + 2 + j, acc);
-    }
+    column_sums<kSampledThreads, true>(Ul, el, T, tid, p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T));
     BN_STAMP(5);
     if (p.ustar_cur) ticket_merge<kSampledThreads>(p, b, wg.blk, smem);   // one-launch mode; the slot rows are dead: their LDS is the merge scratch
 }
@@ -260,13 +253,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
     el[lane] = e;
     __syncthreads();
     float *part = p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T);
-    for (int j = lane; j < 2 * T; j += 64) {
-        const float *col = Ul + j * kUPad;
-        float acc = 0.0f;
-#pragma unroll 16
-        for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(el[q], col[q], acc);
-        part[2 + j] = acc;
-    }
+    column_sums<64, false>(Ul, el, T, lane, part);
     if (lane == 0) { part[0] = zmax; part[1] = esum; }
 }
 

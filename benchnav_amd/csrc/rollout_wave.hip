@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
 
     const float *part_prev = p.part_prev + (size_t)b * p.nblk * (2 + 2 * T);
-    MergeLoads pre;
+    MergeLoads pre{};
     const bool pre_ok = p.mean_from_part && p.nblk <= 64;
     if (pre_ok) pre = merge_issue(part_prev, p.nblk, T, lane);
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     }
     if (p.mean_from_part) {
         float m_unused, S_unused;
-        merge_partials<64>(part_prev, p.nblk, T, ml, sc, sc + p.nblk, lane, m_unused, S_unused, pre_ok ? &pre : nullptr);
+        merge_partials<64>(part_prev, p.nblk, T, ml, sc, sc + p.nblk, lane, m_unused, S_unused, pre_ok, pre);
         for (int j = lane; j < 2 * T; j += 64) mv[j] = ml[j] * ((j & 1) ? p.iv1 : p.iv0);
     } else {
         for (int j = lane; j < 2 * T; j += 64) {
@@ -127,14 +127,23 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     const float *Urow0 = p.U + (size_t)b * T * 2 * Kp + (size_t)wg.blk * kRolloutsPerBlock;
     for (int j = lane; j < 2 * T; j += 64) {
         const float4 *row = reinterpret_cast<const float4 *>(Urow0 + (size_t)j * Kp);
-        float acc = 0.0f;
+        // the summation order of column_sums: quarters of 16 rollouts, (q0 + q1) + (q2 + q3).  A rolled loop over the
+        // quarters on purpose: unrolled, the four independent sums are scheduled side by side and cost the kernel half its
+        // occupancy (127-143 VGPRs instead of 80).
+        float acc = 0.0f, pair = 0.0f;
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            float a_ = 0.0f;
 #pragma unroll
-        for (int q4 = 0; q4 < kRolloutsPerBlock / 4; ++q4) {
-            const float4 v = row[q4];
-            acc = __builtin_fmaf(el[4 * q4 + 0], v.x, acc);
-            acc = __builtin_fmaf(el[4 * q4 + 1], v.y, acc);
-            acc = __builtin_fmaf(el[4 * q4 + 2], v.z, acc);
-            acc = __builtin_fmaf(el[4 * q4 + 3], v.w, acc);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = row[4 * r + q4];
+                a_ = __builtin_fmaf(el[16 * r + 4 * q4 + 0], v.x, a_);
+                a_ = __builtin_fmaf(el[16 * r + 4 * q4 + 1], v.y, a_);
+                a_ = __builtin_fmaf(el[16 * r + 4 * q4 + 2], v.z, a_);
+                a_ = __builtin_fmaf(el[16 * r + 4 * q4 + 3], v.w, a_);
+            }
+            if (r & 1) { pair = pair + a_; acc = (r == 1) ? pair : acc + pair; }
+            else pair = a_;
         }
         part[2 + j] = acc;
     }

@@ -4,10 +4,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b
-b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_timing.so")
+b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ.get("BN_VARIANT", "timing"))
 from benchnav_amd import NativeMPPI, synth
 inst = synth.make_instance(256, seed=0)
-for kern in ("lat", "role"):
+for kern in os.environ.get("BN_KERNELS", "lat,role").split(","):
     pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, stream=0, kernel=kern)
     pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
     stamps = torch.zeros(64 + 4 * 64, dtype=torch.int64, device="cuda")
