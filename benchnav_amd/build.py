@@ -36,10 +36,26 @@ def is_stale() -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    """Compile csrc/*.hip|cpp into lib/libbenchnav_mppi.so for gfx950."""
+    """Compile csrc/*.hip|cpp into lib/libbenchnav_mppi.so for gfx950.
+
+    Safe under concurrent callers (every rank of a torchrun job importing the package at once): one holds an exclusive file
+    lock and builds into private object / library names, then publishes with an atomic rename; the others wait for the lock,
+    find the library fresh and return."""
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():         # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(verbose, extra_flags)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose, extra_flags) -> str:
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
@@ -57,10 +73,12 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
                 other.wait()
             raise RuntimeError(f"hipcc failed on {src}")
         objs.append(obj)
-    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    os.replace(tmp, LIB_PATH)                       # readers see the old library or the new one, never a half-written file
     return LIB_PATH
 
 

@@ -844,7 +844,7 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
     BN_HIP(hipMemcpyAsync(d_st, states_host, B * 3 * 4, hipMemcpyHostToDevice, h->stream));
     bn::SolveParams p = h->p;
     p.state = d_st;
-    BN_HIP(bn::launch_dwa(p, d_act, d_goal, num_actions, d_X, d_c, d_w, d_best, d_bs, h->stream));
+    BN_HIP(bn::launch_dwa(p, d_act, d_goal, num_actions, d_X, d_c, d_w, d_best, d_bs, nullptr, h->stream));
     std::vector<int> best(B);
     BN_HIP(hipMemcpyAsync(best.data(), d_best, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (best_states_host) BN_HIP(hipMemcpyAsync(best_states_host, d_bs, n_bs * 4, hipMemcpyDeviceToHost, h->stream));
@@ -856,6 +856,34 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
         if (best_index_host) best_index_host[b] = best[b];
         if (best_action_host) std::memcpy(best_action_host + b * 2, actions_host + (b * NA + best[b]) * 2, 8);
     }
+    return BN_OK;
+}
+
+int bn_mppi_dwa_forward_async(bn_mppi_t *h, const float *states_device, float *prev_action_device, const float a_lim_host[2],
+                              float dwa_delta_t, int32_t num_lin_vel, int32_t num_ang_vel, const float *path_device, int32_t num_path,
+                              float lookahead, float *best_states_device)
+{
+    if (!h || !states_device || !prev_action_device || !a_lim_host) return fail(BN_ERR_INVALID, "null argument");
+    const int64_t NA = (int64_t)num_lin_vel * num_ang_vel;
+    if (num_lin_vel < 1 || num_ang_vel < 1 || NA > 1024) return fail(BN_ERR_INVALID, "num_lin_vel * num_ang_vel must be in [1, 1024]");
+    if (path_device && num_path < 1) return fail(BN_ERR_INVALID, "a reference path needs at least one point");
+    if (!h->map_set || !h->goal_set) return fail(BN_ERR_STATE, "set_map and set_goal must precede dwa_forward");
+    BN_BIND(h);
+    if (int rc = flush_tail(h)) return rc;
+    const size_t B = h->p.B, T1 = h->p.T + 1;
+    // the scratch layout of bn_mppi_dwa_solve: actions | stage goal | X | cost | w | best | best states | states
+    const size_t n_act = B * NA * 2, n_goal = B * 2, n_X = B * NA * T1 * 3, n_c = B * NA, n_bs = B * T1 * 3;
+    const size_t floats = n_act + n_goal + n_X + 2 * n_c + B + n_bs + B * 3;
+    if (floats * 4 > h->scratch_bytes) BN_HIP(hipStreamSynchronize(h->stream));      // growing frees the old block: nothing may still use it
+    if (int rc = ensure_scratch(h, floats * 4)) return rc;
+    float *d_act = h->d_scratch, *d_goal = d_act + n_act, *d_X = d_goal + n_goal, *d_c = d_X + n_X, *d_w = d_c + n_c;
+    int *d_best = reinterpret_cast<int *>(d_w + n_c);
+    float *d_bs = best_states_device ? best_states_device : d_w + n_c + B;
+    bn::SolveParams p = h->p;
+    p.state = states_device;
+    BN_HIP(bn::launch_dwa_window(p, prev_action_device, a_lim_host, dwa_delta_t, num_lin_vel, num_ang_vel, path_device, num_path, lookahead,
+                                 d_act, d_goal, h->stream));
+    BN_HIP(bn::launch_dwa(p, d_act, d_goal, (int)NA, d_X, d_c, d_w, d_best, d_bs, prev_action_device, h->stream));
     return BN_OK;
 }
 
@@ -872,6 +900,16 @@ int bn_mppi_dwa_buffers(bn_mppi_t *h, int32_t num_actions, const float **states_
     if (states_all_device) *states_all_device = d_X;
     if (costs_device) *costs_device = d_X + n_X;
     if (weights_device) *weights_device = d_X + n_X + n_c;
+    return BN_OK;
+}
+
+int bn_mppi_dwa_candidates(bn_mppi_t *h, int32_t num_actions, const float **actions_device, const float **stage_goal_device)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (num_actions < 1 || num_actions > 1024) return fail(BN_ERR_INVALID, "num_actions must be in [1, 1024]");
+    if (!h->d_scratch) return fail(BN_ERR_STATE, "no DWA solve has run");
+    if (actions_device) *actions_device = h->d_scratch;                                                    // (B, num_actions, 2)
+    if (stage_goal_device) *stage_goal_device = h->d_scratch + (size_t)h->p.B * num_actions * 2;            // (B, 2)
     return BN_OK;
 }
 

@@ -119,7 +119,10 @@ hipError_t launch_reroll(const SolveParams &p, EpsMode mode, int b, const int *i
 hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s);
 bool sampled_fused(const SolveParams &p);   // the sampled launch merges by ticket and carries the previous tail (LDS-window variant)
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
-                      float *w, int *best, float *best_states, hipStream_t s);
+                      float *w, int *best, float *best_states, float *best_action, hipStream_t s);
+// DWA's host geometry on the device: window grid (B, nv*nw, 2) around prev_action (B,2) and the sub-goal (B,2) on `path` (P,2)
+hipError_t launch_dwa_window(const SolveParams &p, const float *prev_action, const float a_lim[2], float dwa_dt, int nv, int nw,
+                             const float *path, int P, float lookahead, float *actions, float *stage_goal, hipStream_t s);
 
 hipError_t launch_env_step(const SolveParams &p, const float *actions, float *states, float *reward, int *terminated, const float *z,
                            uint64_t step, hipStream_t s);

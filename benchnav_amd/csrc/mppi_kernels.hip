@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void reroll_kernel(const SolveParams p, int b,
 template <int GEO, bool LDSWIN>
 __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ actions, const float *__restrict__ stage_goal,
                            int NA, float *__restrict__ Xall, float *__restrict__ cost_out, float *__restrict__ w_out,
-                           int *__restrict__ best_out, float *__restrict__ best_states)
+                           int *__restrict__ best_out, float *__restrict__ best_states, float *__restrict__ best_action)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = p.T;
@@ -162,11 +162,101 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
     float tot = 0.0f;
     for (int i = 0; i < nw; ++i) tot += red[i];
     if (active) w_out[(size_t)b * NA + tid] = e / tot;
-    if (tid == 0) best_out[b] = imin;
+    if (tid == 0) {
+        best_out[b] = imin;
+        if (best_action) {                             // optimal_action_seq = actions[argmin] (dwa.py:140); also the next window's centre (dwa.py:147)
+            best_action[b * 2 + 0] = actions[((size_t)b * NA + imin) * 2 + 0];
+            best_action[b * 2 + 1] = actions[((size_t)b * NA + imin) * 2 + 1];
+        }
+    }
     // optimal_state_seq = the argmin candidate's trajectory (dwa.py:139-143): its stores are complete and visible to
     // the workgroup since the barriers above
     if (Xall && best_states)
         for (int i = tid; i < (T + 1) * 3; i += nthreads) best_states[(size_t)b * (T + 1) * 3 + i] = Xall[((size_t)b * NA + imin) * (T + 1) * 3 + i];
+}
+
+// ------------------------------------------------------------------------------
+// DWA host geometry on the device (so that DWA.forward needs no host round trip): the dynamic window grid and the
+// sub-goal.  grid = B, block = 256.
+//   window   dwa.py:168-199: lo = max(u_min, prev - a_lim * dt), hi = min(u_max, prev + a_lim * dt) around the previous first
+//            control; vs = linspace(lo_v, hi_v, nv), ws = linspace(lo_w, hi_w, nw); actions = cartesian_prod(vs, ws) (v major).
+//            linspace as ATen's scalar kernel computes it: step = (end - start) / (n - 1); element i < n/2 is
+//            start + step * i, the others end - step * (n - 1 - i).  (On AVX2 hosts torch's vectorised path evaluates the
+//            first 8 elements from `start` alone, so torch itself is machine dependent in the last bit; this is the form
+//            AVX-512 hosts and every scalar tail use.)
+//   sub-goal dwa.py:240-244 + 260-285, evaluated like the reference on candidate 0's ALIASED slot-0 state (the start state
+//            advanced by one un-clamped, un-wrapped step of candidate 0 = (lo_v, lo_w)): nearest path point with
+//            |bearing| < pi/2 and distance > lookahead -- the first point at that distance -- else the path's end.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_at(float start, float end, int n, int i)
+{
+    if (n == 1) return start;
+    const float step = (end - start) / (float)(n - 1);
+    return i < n / 2 ? start + step * (float)i : end - step * (float)(n - 1 - i);
+}
+
+template <int GEO>
+__global__ __launch_bounds__(256) void dwa_window_kernel(const SolveParams p, const float *__restrict__ prev_action, float alim0, float alim1,
+                                                         float dwa_dt, int nv, int nw, const float *__restrict__ path, int P, float lookahead,
+                                                         float *__restrict__ actions, float *__restrict__ stage_goal)
+{
+    __shared__ float red[8];
+    __shared__ int redi[8];
+    __shared__ float sel[3];
+    const int b = blockIdx.x, tid = threadIdx.x, NA = nv * nw;
+    const float pv = prev_action[b * 2 + 0], pw = prev_action[b * 2 + 1];
+    const float lo0 = fmaxf(p.umin0, pv - alim0 * dwa_dt), hi0 = fminf(p.umax0, pv + alim0 * dwa_dt);
+    const float lo1 = fmaxf(p.umin1, pw - alim1 * dwa_dt), hi1 = fminf(p.umax1, pw + alim1 * dwa_dt);
+    for (int k = tid; k < NA; k += 256) {
+        const int iv = k / nw, iw = k - iv * nw;
+        actions[((size_t)b * NA + k) * 2 + 0] = linspace_at(lo0, hi0, nv, iv);
+        actions[((size_t)b * NA + k) * 2 + 1] = linspace_at(lo1, hi1, nw, iw);
+    }
+    if (!path || P < 1) {                               // no reference path: the stage cost runs against the goal (dwa.py:243-247)
+        if (tid < 2) stage_goal[b * 2 + tid] = p.goal[b * 2 + tid];
+        return;
+    }
+    if (tid == 0) {                                     // candidate 0's slot 0 after the rollouts (aliasing, robot_model.py:86-88)
+        const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
+        const float sx = p.state[b * 3 + 0], sy = p.state[b * 3 + 1], sth = p.state[b * 3 + 2];
+        const Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
+        const float trav = trav_lookup<GEO, false, true>(p, nullptr, map, w, sx, sy);
+        const float v = clampf(linspace_at(lo0, hi0, nv, 0), p.umin0, p.umax0), om = clampf(linspace_at(lo1, hi1, nw, 0), p.umin1, p.umax1);
+        float sn, cs;
+        sincos_spec(sth, sn, cs);
+        sel[0] = sx + ((trav * v) * cs) * p.dt;
+        sel[1] = sy + ((trav * v) * sn) * p.dt;
+        sel[2] = sth + (trav * om) * p.dt;
+    }
+    __syncthreads();
+    const float x = sel[0], y = sel[1], th = sel[2];
+    float best = INFINITY;
+    for (int i = tid; i < P; i += 256) {
+        const float dx = path[2 * i] - x, dy = path[2 * i + 1] - y;
+        const float dist = sqrt_cr(dx * dx + dy * dy);
+        const float ang = atan2f(dy, dx) - th;
+        if (fabsf(ang) < kPi / 2.0f && dist > lookahead) best = fminf(best, dist);
+    }
+    best = -wave_max(-best);
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    best = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    int idx = 0x7fffffff;
+    if (best < INFINITY)
+        for (int i = tid; i < P; i += 256) {
+            const float dx = path[2 * i] - x, dy = path[2 * i + 1] - y;
+            if (sqrt_cr(dx * dx + dy * dy) == best) { idx = i; break; }      // torch.where(distances == min)[0][0]: over ALL points
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o));
+    if ((tid & 63) == 0) redi[tid >> 6] = idx;
+    __syncthreads();
+    if (tid == 0) {
+        idx = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        if (best == INFINITY || idx >= P) idx = P - 1;                       // nothing ahead: the path's last point
+        stage_goal[b * 2 + 0] = path[2 * idx];
+        stage_goal[b * 2 + 1] = path[2 * idx + 1];
+    }
 }
 
 // ------------------------------------------------------------------------------
@@ -370,8 +460,19 @@ hipError_t launch_reroll(const SolveParams &p, EpsMode mode, int b, const int *i
     }
 }
 
+hipError_t launch_dwa_window(const SolveParams &p, const float *prev_action, const float a_lim[2], float dwa_dt, int nv, int nw,
+                             const float *path, int P, float lookahead, float *actions, float *stage_goal, hipStream_t s)
+{
+    switch (geo_of(p)) {
+    case kGeoPow2Origin0: dwa_window_kernel<kGeoPow2Origin0><<<dim3(p.B), dim3(256), 0, s>>>(p, prev_action, a_lim[0], a_lim[1], dwa_dt, nv, nw, path, P, lookahead, actions, stage_goal); break;
+    case kGeoPow2: dwa_window_kernel<kGeoPow2><<<dim3(p.B), dim3(256), 0, s>>>(p, prev_action, a_lim[0], a_lim[1], dwa_dt, nv, nw, path, P, lookahead, actions, stage_goal); break;
+    default: dwa_window_kernel<kGeoGeneral><<<dim3(p.B), dim3(256), 0, s>>>(p, prev_action, a_lim[0], a_lim[1], dwa_dt, nv, nw, path, P, lookahead, actions, stage_goal); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
-                      float *w, int *best, float *best_states, hipStream_t s)
+                      float *w, int *best, float *best_states, float *best_action, hipStream_t s)
 {
     const int threads = ((NA + 63) / 64) * 64;
     const size_t lds = sizeof(float) * ((size_t)p.WN * p.WN + 32);
@@ -379,8 +480,8 @@ hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *s
 #define BN_DWA_LAUNCH(GEO_)                                                                                          \
     do {                                                                                                             \
         if (win) { hipError_t e = ensure_lds(dwa_kernel<GEO_, true>, lds); if (e != hipSuccess) return e;           \
-                   dwa_kernel<GEO_, true><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best, best_states); } \
-        else { dwa_kernel<GEO_, false><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best, best_states); }   \
+                   dwa_kernel<GEO_, true><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best, best_states, best_action); } \
+        else { dwa_kernel<GEO_, false><<<dim3(p.B), dim3(threads), lds, s>>>(p, actions, stage_goal, NA, Xall, cost, w, best, best_states, best_action); }   \
     } while (0)
     switch (geo_of(p)) {
     case kGeoPow2Origin0: BN_DWA_LAUNCH(kGeoPow2Origin0); break;

@@ -1,10 +1,12 @@
 """MI355X-native Dynamic Window Approach with the reference's Python interface ("next" row N3).
 
 Mirror of `DWA(nn.Module)` in the reference's src/planners/local_planners/dwa.py (constructor :17-31,
-forward :116, update_reference_path :155, get_top_samples :287).  The candidate rollouts, costs, argmin and
-weights run in the HIP kernel behind bn_mppi_dwa_solve; the two tiny pieces of host geometry -- the dynamic
-window grid (dwa.py:168-199) and the sub-goal pick on the reference path (dwa.py:260-285) -- are computed with
-torch on the CPU as the reference does, so the candidate set is the reference's, value for value.
+forward :116, update_reference_path :155, get_top_samples :287).  forward() is ONE asynchronous C call
+(bn_mppi_dwa_forward_async): the dynamic window grid (dwa.py:168-199), the sub-goal pick on the reference path
+(dwa.py:240-244, 260-285: from candidate 0's aliased slot-0 state, as the reference does), the candidate rollouts,
+costs, argmin and weights all run on the device; nothing returns to the host.  `_generate_actions`, `_sub_goal_state`
+and `_select_sub_goal` restate the two pieces of geometry with torch-CPU operations in the reference's order (what the
+tests compare the device path with); forward() does not call them.
 """
 from __future__ import annotations
 
@@ -14,6 +16,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import ctypes as C
+
+from . import _capi
 from .mppi import _DevArray, _planner_inputs
 from .native import NativeMPPI
 
@@ -49,16 +54,19 @@ class DWA(nn.Module):
         self._native = NativeMPPI(horizon=horizon, num_samples=64, grid_size=inp["grid_size"], resolution=inp["resolution"],
                                   x_limits=inp["x_limits"], y_limits=inp["y_limits"],
                                   u_min=self._u_min.tolist(), u_max=self._u_max.tolist(),
-                                  stuck_threshold=inp["stuck_threshold"], device_id=self._device.index, stream=0)
+                                  stuck_threshold=inp["stuck_threshold"], device_id=self._device.index,
+                                  stream=torch.cuda.current_stream(self._device).cuda_stream)
         self._risk_cpu = inp["risks"].detach().to("cpu", torch.float32).contiguous()
         self._grid = (inp["grid_size"], inp["resolution"], inp["x_limits"], inp["y_limits"])
         self._native.set_map(self._risk_cpu.numpy())
         self._native.set_goal(self._goal.numpy())
-        n = num_lin_vel * num_ang_vel
         self._previous_action_seq = torch.zeros(horizon, dim_control, device=self._device, dtype=dtype)
-        self._state_seq_batch = torch.zeros(n, horizon + 1, dim_state, device=self._device, dtype=dtype)
-        self._weights = torch.zeros(n, device=self._device, dtype=dtype)
+        self._prev_buf = torch.zeros(1, dim_control, device=self._device, dtype=dtype)      # the window's centre, updated by the kernel
+        self._prev_ptr = None                       # storage of the _previous_action_seq the buffer already mirrors
+        self._a_lim_c = (C.c_float * 2)(float(self._a_lim[0]), float(self._a_lim[1]))
+        self._solved = False
         self.reference_path: Optional[torch.Tensor] = None
+        self._path_dev: Optional[torch.Tensor] = None
 
     # -- host geometry (tiny; torch-CPU like the reference so the numbers are the reference's) -----------------
     def _generate_actions(self) -> torch.Tensor:
@@ -105,30 +113,67 @@ class DWA(nn.Module):
         if reference_path is not None:
             assert reference_path.shape[1] == 2, "reference_path must be a tensor of shape (num_positions, 2)"
             self.reference_path = reference_path.detach().to("cpu", self._dtype)
+            self._path_dev = self.reference_path.to(self._device).contiguous()
 
     # -- the solve -------------------------------------------------------------------------------------------------
     def forward(self, state: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Returns (optimal_action_seq (1,2), optimal_state_seq (1,T+1,3)) on the planner's device (dwa.py:116-153)."""
+        """Returns (optimal_action_seq (1,2), optimal_state_seq (1,T+1,3)) on the planner's device (dwa.py:116-153),
+        stream-ordered like any torch op: one C call, no host synchronisation."""
         if not torch.is_tensor(state):
             state = torch.tensor(state, dtype=self._dtype)
         assert state.shape == (self._dim_state,), "state must be a tensor of shape (dim_state,)"
-        st = state.detach().to("cpu", self._dtype)
-        actions = self._generate_actions()
-        sub_goal = self._select_sub_goal(self._sub_goal_state(st, actions[0])) if self.reference_path is not None else None
-        out = self._native.dwa_solve(st.numpy(), actions.numpy(), None if sub_goal is None else sub_goal.numpy(), full=False)
-        best = int(out["best_index"][0])
-        n = actions.shape[0]
-        optimal_action_seq = actions[best].unsqueeze(0).to(self._device)
-        optimal_state_seq = torch.from_numpy(out["best_states"]).to(self._device)
-        self._previous_action_seq = optimal_action_seq                     # dwa.py:147
-        # the candidate batch stays on the device: views of the library's buffers, copied into tensors the caller may keep
+        if state.device != self._device or state.dtype != self._dtype or not state.is_contiguous():
+            state = state.detach().to(self._device, self._dtype).contiguous()
+        prev = self._previous_action_seq
+        if prev.data_ptr() != self._prev_ptr:                           # set by the caller (or the initial zeros): mirror its first row
+            self._prev_buf.copy_(prev[:1].to(self._device, self._dtype))
+        n = self._num_lin_vel * self._num_ang_vel
+        x_opt = torch.empty(1, self._horizon + 1, 3, device=self._device, dtype=self._dtype)
+        path = self._path_dev
+        _capi.check(self._native._lib.bn_mppi_dwa_forward_async(
+            self._native._h, state.data_ptr(), self._prev_buf.data_ptr(), self._a_lim_c, self._delta_t, self._num_lin_vel,
+            self._num_ang_vel, None if path is None else path.data_ptr(), 0 if path is None else path.shape[0],
+            self._lookahead_distance, x_opt.data_ptr()))
+        self._keep = state
+        optimal_action_seq = self._prev_buf.clone()                     # (1,2): the argmin action, written by the kernel
+        self._previous_action_seq = optimal_action_seq                  # dwa.py:147
+        self._prev_ptr = optimal_action_seq.data_ptr()
+        self._solved = True
+        return optimal_action_seq, x_opt
+
+    def _scratch_views(self):
+        n = self._num_lin_vel * self._num_ang_vel
         xp, cp, wp = self._native.dwa_buffers(n)
-        self._state_seq_batch = torch.as_tensor(_DevArray(xp, (n, self._horizon + 1, 3)), device=self._device).clone()
-        self._costs = torch.as_tensor(_DevArray(cp, (n,)), device=self._device).clone()
-        self._weights = torch.as_tensor(_DevArray(wp, (n,)), device=self._device).clone()
-        return optimal_action_seq, optimal_state_seq
+        return (torch.as_tensor(_DevArray(xp, (n, self._horizon + 1, 3)), device=self._device),
+                torch.as_tensor(_DevArray(cp, (n,)), device=self._device), torch.as_tensor(_DevArray(wp, (n,)), device=self._device))
+
+    @property
+    def _state_seq_batch(self) -> torch.Tensor:
+        """(n, T+1, 3) candidate trajectories of the latest forward(): a view of the library's buffer (next call overwrites it)."""
+        if not self._solved:
+            return torch.zeros(self._num_lin_vel * self._num_ang_vel, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
+        return self._scratch_views()[0]
+
+    @property
+    def _costs(self) -> torch.Tensor:
+        return self._scratch_views()[1]
+
+    @property
+    def _weights(self) -> torch.Tensor:
+        if not self._solved:
+            return torch.zeros(self._num_lin_vel * self._num_ang_vel, device=self._device, dtype=self._dtype)
+        return self._scratch_views()[2]
+
+    def last_candidates(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(actions (n,2), sub_goal (2,)) the latest forward() used, as computed on the device."""
+        n = self._num_lin_vel * self._num_ang_vel
+        a, g = C.c_void_p(), C.c_void_p()
+        _capi.check(self._native._lib.bn_mppi_dwa_candidates(self._native._h, n, C.byref(a), C.byref(g)))
+        return (torch.as_tensor(_DevArray(a.value, (n, 2)), device=self._device).clone(),
+                torch.as_tensor(_DevArray(g.value, (2,)), device=self._device).clone())
 
     def get_top_samples(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """All candidates sorted by weight, best first (dwa.py:287-299)."""
-        order = torch.argsort(self._weights, descending=True)
-        return self._state_seq_batch[order], self._weights[order]
+        X, _, w = self._scratch_views()
+        order = torch.argsort(w, descending=True)
+        return X[order], w[order]

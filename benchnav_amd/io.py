@@ -21,7 +21,8 @@ from torch.distributions import Normal
 @dataclass
 class MapInstance:
     grid_size: int
-    tensors: Dict[str, torch.Tensor]                      # heights, slopes, t_classes, colors (float32, CPU)
+    tensors: Dict[str, torch.Tensor]                      # heights, slopes, t_classes, colors: CPU, dtypes as stored (t_classes is
+                                                          # int64 in the reference's files, terrain_properties.py:430)
     latent_mean: torch.Tensor                             # (G,G)
     latent_std: torch.Tensor                              # (G,G)
     pred_mean: Optional[torch.Tensor] = None              # (G,G) predicted slip mean, if stored
@@ -37,10 +38,17 @@ def _mean_std(dist) -> Tuple[torch.Tensor, torch.Tensor]:
     return m.detach().to("cpu", torch.float32).contiguous(), s.detach().to("cpu", torch.float32).contiguous()
 
 
-def load_instance(path: str) -> MapInstance:
-    """Read a BenchNav instance file into plain CPU float32 tensors."""
-    item = torch.load(path, map_location="cpu", weights_only=False)     # the file pickles torch.distributions.Normal
-    tensors = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in item["tensors"].items()}
+def load_instance(path: str, trusted: bool = False) -> MapInstance:
+    """Read a BenchNav instance file into plain CPU tensors (stored dtypes kept; the planner-facing arrays -- latent and
+    predicted slip mean / std -- as float32).  The file pickles torch.distributions.Normal objects: by default it is read
+    with torch's restricted unpickler and only that class allow-listed; trusted=True falls back to the full unpickler for
+    files from a source you control (what the reference's own torch.load does, test_mppi.py:42)."""
+    if trusted:
+        item = torch.load(path, map_location="cpu", weights_only=False)
+    else:
+        with torch.serialization.safe_globals([Normal]):
+            item = torch.load(path, map_location="cpu", weights_only=True)
+    tensors = {k: v.detach().to("cpu").contiguous() for k, v in item["tensors"].items()}
     dists = item["distributions"]
     lat_m, lat_s = _mean_std(dists["latent_models"])
     G = lat_m.shape[-1]

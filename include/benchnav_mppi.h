@@ -247,6 +247,17 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
  * handle's scratch memory): states_all (B,num_actions,T+1,3), costs and weights (B,num_actions). */
 int bn_mppi_dwa_buffers(bn_mppi_t *h, int32_t num_actions, const float **states_all_device, const float **costs_device,
                         const float **weights_device);
+/* DWA.forward with nothing on the host (dwa.py:116-153 incl. _generate_actions :168-199 and the sub-goal of :240-244,
+ * 260-285): the window grid around prev_action_device (B,2) -- linspace x linspace, v major -- and the sub-goal on
+ * path_device (num_path,2; NULL: the goal) are computed on the device, the sub-goal like the reference from candidate 0's
+ * aliased slot-0 state; then the candidates are rolled out and costed as in bn_mppi_dwa_solve.  Only enqueues.
+ * prev_action_device is updated in place with the argmin action (dwa.py:147: the next window's centre) -- it IS
+ * optimal_action_seq; best_states_device (B,T+1,3) may be NULL.  The candidate batch stays in the handle's scratch:
+ * bn_mppi_dwa_buffers (states, costs, weights) and bn_mppi_dwa_candidates (the window grid and the sub-goal used). */
+int bn_mppi_dwa_forward_async(bn_mppi_t *h, const float *states_device, float *prev_action_device, const float a_lim_host[2],
+                              float dwa_delta_t, int32_t num_lin_vel, int32_t num_ang_vel, const float *path_device, int32_t num_path,
+                              float lookahead, float *best_states_device);
+int bn_mppi_dwa_candidates(bn_mppi_t *h, int32_t num_actions, const float **actions_device, const float **stage_goal_device);
 int bn_mppi_sync(bn_mppi_t *h);
 /* Enqueue the pending tail (if any) without waiting. */
 int bn_mppi_flush(bn_mppi_t *h);

@@ -461,8 +461,50 @@ def run_episode_case():
           f"(terminated {ep_term[-1]}) -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def run_instance_io_case():
+    """N4: a map-instance file written by benchnav_amd.io.save_instance (the layout of dataset_generator.py:302-305) is read by
+    the REFERENCE's own loading path (test_mppi.py:42-44 -> GridMap, grid_map.py:100-143) and what the reference's objects hold
+    afterwards is stored: tensors, the latent / predicted Normal's mean and std, lookups through get_values_at_positions, and the
+    CVaR risk map its UnicycleModel infers (with the draw captured).  The committed file instance_000_000.pt is data, written by
+    this repo's code."""
+    from benchnav_amd import io as bio
+    G, res = 8, 0.5
+    g = torch.Generator().manual_seed(5)
+    inst = bio.MapInstance(grid_size=G,
+                           tensors={"heights": torch.rand(G, G, generator=g), "slopes": torch.rand(G, G, generator=g) * 0.3,
+                                    "t_classes": torch.randint(0, 10, (G, G), generator=g), "colors": torch.rand(3, G, G, generator=g)},
+                           latent_mean=smooth_risk_map(G, 31) * 0.6, latent_std=slip_std_map(G, 31),
+                           pred_mean=smooth_risk_map(G, 32) * 0.7, pred_std=slip_std_map(G, 32))
+    path = os.path.join(HERE, "instance_000_000.pt")
+    bio.save_instance(path, inst)
+    data_item = torch.load(path, weights_only=False)                 # the reference's own call (test_mppi.py:42)
+    gm = GridMap(grid_size=G, resolution=res, tensors=data_item["tensors"], distributions=data_item["distributions"],
+                 instance_name="000_000", device="cpu")
+    for k, v in inst.tensors.items():
+        assert gm.tensors[k].dtype == v.dtype and torch.equal(gm.tensors[k], v), k
+    assert torch.equal(gm.distributions["latent_models"].mean, inst.latent_mean) and torch.equal(gm.distributions["predictions"].stddev, inst.pred_std)
+    pos = torch.tensor([[[0.1, 0.2, 0.0], [3.3, 1.9, 0.0], [3.99, 0.0, 0.0], [-1.0, 9.0, 0.0]]])
+    looked = {k: gm.get_values_at_positions(gm.tensors[k], pos).numpy() for k in ("heights", "slopes", "t_classes")}
+    lat = gm.get_values_at_positions(gm.distributions["latent_models"], pos)
+    torch.manual_seed(8)
+    dyn = UnicycleModel(gm, ModelConfig(mode="inference", inference_metric="cvar", confidence_value=0.9), device="cpu")
+    n_used = 1000                                                    # _infer_risk_map's default num_samples
+    torch.manual_seed(8)
+    z = torch.empty(n_used, G, G).normal_()
+    out = dict(G=G, res=res, positions=pos.numpy(), latent_mean_at=lat.mean.numpy(), latent_std_at=lat.stddev.numpy(),
+               risk_cvar=dyn._traversability_model._risks.numpy(), z=z.numpy().astype(np.float32), torch_version=torch.__version__,
+               **{f"tensor_{k}": gm.tensors[k].numpy() for k in gm.tensors}, **{f"at_{k}": v for k, v in looked.items()},
+               latent_mean=gm.distributions["latent_models"].mean.numpy(), latent_std=gm.distributions["latent_models"].stddev.numpy(),
+               pred_mean=gm.distributions["predictions"].mean.numpy(), pred_std=gm.distributions["predictions"].stddev.numpy())
+    p_ = os.path.join(HERE, "instance.npz")
+    np.savez_compressed(p_, **out)
+    print(f"instance       G={G}: written by benchnav_amd.io, read by the reference's GridMap -> {os.path.getsize(p_)/1024:.0f} KiB + {os.path.getsize(path)/1024:.0f} KiB .pt")
+
+
 def main():
     pi = math.pi
+    if sys.argv[1:] == ["instance"]:
+        return run_instance_io_case()
     if sys.argv[1:] == ["sampled"]:
         return run_sampled_case()
     if sys.argv[1:] == ["dwa"]:
@@ -473,6 +515,7 @@ def main():
         return run_episode_case()
     run_env_case()
     run_episode_case()
+    run_instance_io_case()
     run_riskmap_case()
     run_sampled_case()
     run_dwa_case()

@@ -94,6 +94,8 @@ def test_kernel_matches_oracle_and_reference():
 
 @pytest.mark.gpu
 def test_drop_in_class_follows_the_reference_run():
+    """forward() is one asynchronous device call: window grid, sub-goal (from candidate 0's aliased slot), rollouts, costs,
+    argmin.  Teacher-forced on the reference's previous action; every piece against the fixture."""
     import torch
     from helpers import FakeDynamics, FakeGridMap, FakeObjectives
     from benchnav_amd import DWA
@@ -105,17 +107,50 @@ def test_drop_in_class_follows_the_reference_run():
                  a_lim=torch.tensor(fx["a_lim"]), delta_t=float(fx["delta_t"]), lookahead_distance=float(fx["lookahead"]),
                  num_lin_vel=int(fx["nv"]), num_ang_vel=int(fx["nw"]))
     solver.update_reference_path(torch.tensor(fx["path"]))
-    same_build = str(fx["torch_version"]) == torch.__version__
+    p = _params(fx)
     for i in range(int(fx["n_solves"])):
         state = torch.tensor(fx[f"state_{i}"])
-        if i > 0:                                        # teacher forcing: the window follows the REFERENCE's previous pick
-            solver._previous_action_seq = torch.tensor(fx[f"a_opt_{i - 1}"], device="cuda")
-        acts = solver._generate_actions()
-        assert np.abs(acts.numpy() - fx[f"actions_{i}"]).max() <= (0 if same_build else 1e-6)
-        assert np.array_equal(solver._select_sub_goal(solver._sub_goal_state(state, acts[0])).numpy(), fx[f"sub_goal_{i}"])
+        solver._previous_action_seq = torch.tensor(fx[f"prev_action_{i}"], device="cuda").unsqueeze(0)     # the REFERENCE's previous pick
         a_opt, x_opt = solver(state)
         assert a_opt.shape == (1, 2) and x_opt.shape == (1, int(fx["T"]) + 1, 3) and a_opt.is_cuda
+        acts, sub_goal = solver.last_candidates()
+        # torch.linspace itself differs in the last bit between AVX2 and AVX-512 hosts (vectorised head); the device uses the scalar form
+        assert np.abs(acts.cpu().numpy() - fx[f"actions_{i}"]).max() <= 1e-6
+        assert np.array_equal(sub_goal.cpu().numpy(), fx[f"sub_goal_{i}"]), i
+        orc = O.dwa(p, fx["R"], fx[f"state_{i}"], acts.cpu().numpy(), sub_goal.cpu().numpy())
+        assert np.array_equal(solver._state_seq_batch.cpu().numpy(), orc["X"]) and np.array_equal(solver._costs.cpu().numpy(), orc["cost"])
+        assert np.array_equal(a_opt.cpu().numpy()[0], acts.cpu().numpy()[orc["best"]])
         assert np.abs(a_opt.cpu().numpy() - fx[f"a_opt_{i}"]).max() <= 1e-6
         assert np.abs(x_opt[0].cpu().numpy() - fx[f"x_opt_{i}"]).max() <= 1e-4
+        assert torch.equal(solver._previous_action_seq, a_opt)                                # dwa.py:147
         top_s, top_w = solver.get_top_samples()
         assert top_s.shape == (100, int(fx["T"]) + 1, 3) and torch.all(top_w[:-1] >= top_w[1:])
+    # free-running: the window follows the solver's own previous pick without touching the host
+    solver._previous_action_seq = torch.zeros(int(fx["T"]), 2, device="cuda")
+    state = torch.tensor(fx["state_0"], device="cuda")
+    for i in range(3):
+        a_opt, x_opt = solver(state)
+        assert np.abs(a_opt.cpu().numpy() - fx[f"a_opt_{i}"]).max() <= 1e-6, i
+        state = x_opt[0, 3].clone()
+        state[2] = (state[2] + np.pi) % (2 * np.pi) - np.pi
+
+
+@pytest.mark.gpu
+def test_host_restatement_of_the_window_matches_the_device():
+    import torch
+    from helpers import FakeDynamics, FakeGridMap, FakeObjectives
+    from benchnav_amd import DWA
+    fx = _fx()
+    dyn = FakeDynamics(fx["R"], FakeGridMap(int(fx["G"]), float(fx["res"])))
+    solver = DWA(horizon=int(fx["T"]), dim_state=3, dim_control=2, dynamics=dyn, objectives=FakeObjectives(torch.tensor(fx["goal"]), float(fx["thr"])),
+                 a_lim=torch.tensor(fx["a_lim"]), delta_t=float(fx["delta_t"]), num_lin_vel=7, num_ang_vel=13)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        prev = torch.tensor([[rng.uniform(0, 1), rng.uniform(-1, 1)]], dtype=torch.float32)
+        solver._previous_action_seq = prev.cuda()
+        solver(torch.tensor(fx["state_0"]))
+        acts, sub_goal = solver.last_candidates()
+        solver._previous_action_seq = prev.cuda()
+        host = solver._generate_actions()
+        assert host.shape == (91, 2) and np.abs(acts.cpu().numpy() - host.numpy()).max() <= 1e-6
+        assert np.array_equal(sub_goal.cpu().numpy(), fx["goal"])           # no reference path: the goal
