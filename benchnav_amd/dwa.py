@@ -62,7 +62,7 @@ class DWA(nn.Module):
         self._native.set_goal(self._goal.numpy())
         self._previous_action_seq = torch.zeros(horizon, dim_control, device=self._device, dtype=dtype)
         self._prev_buf = torch.zeros(1, dim_control, device=self._device, dtype=dtype)      # the window's centre, updated by the kernel
-        self._prev_ptr = None                       # storage of the _previous_action_seq the buffer already mirrors
+        self._prev_seen = (None, -1)                # (tensor object, its version) of the _previous_action_seq the buffer already mirrors
         self._a_lim_c = (C.c_float * 2)(float(self._a_lim[0]), float(self._a_lim[1]))
         self._solved = False
         self.reference_path: Optional[torch.Tensor] = None
@@ -125,8 +125,8 @@ class DWA(nn.Module):
         if state.device != self._device or state.dtype != self._dtype or not state.is_contiguous():
             state = state.detach().to(self._device, self._dtype).contiguous()
         prev = self._previous_action_seq
-        if prev.data_ptr() != self._prev_ptr:                           # set by the caller (or the initial zeros): mirror its first row
-            self._prev_buf.copy_(prev[:1].to(self._device, self._dtype))
+        if prev is not self._prev_seen[0] or prev._version != self._prev_seen[1]:      # assigned or modified by the caller (or the
+            self._prev_buf.copy_(prev[:1].to(self._device, self._dtype))               # initial zeros): mirror its first row
         n = self._num_lin_vel * self._num_ang_vel
         x_opt = torch.empty(1, self._horizon + 1, 3, device=self._device, dtype=self._dtype)
         path = self._path_dev
@@ -137,7 +137,7 @@ class DWA(nn.Module):
         self._keep = state
         optimal_action_seq = self._prev_buf.clone()                     # (1,2): the argmin action, written by the kernel
         self._previous_action_seq = optimal_action_seq                  # dwa.py:147
-        self._prev_ptr = optimal_action_seq.data_ptr()
+        self._prev_seen = (optimal_action_seq, optimal_action_seq._version)
         self._solved = True
         return optimal_action_seq, x_opt
 
