@@ -25,6 +25,7 @@ BN_FLAG_WAVE_KERNEL = 128
 BN_FLAG_ROLE_KERNEL = 256
 BN_FLAG_LEAN = 512
 BN_FLAG_LAT_KERNEL = 1024
+BN_FLAG_NO_OVERLAP = 2048
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
 ABI_VERSION = 1
 

@@ -68,7 +68,9 @@ struct bn_mppi {
     // device buffers
     float *d_map = nullptr, *d_state = nullptr, *d_goal = nullptr, *d_mean = nullptr, *d_eps = nullptr;
     float *d_X = nullptr, *d_U = nullptr, *d_w = nullptr, *d_cost_out = nullptr;
-    float *d_cost[2] = {nullptr, nullptr}, *d_part[2] = {nullptr, nullptr}, *d_state_copy[2] = {nullptr, nullptr};
+    // per-solve buffers rotate over THREE slots (solve i uses slot i % 3): with overlapped launches (see solve_n_overlapped)
+    // solve i+2 may start while solve i+1's aux workgroup still reads solve i's slot
+    float *d_cost[3] = {nullptr, nullptr, nullptr}, *d_part[3] = {nullptr, nullptr, nullptr}, *d_state_copy[3] = {nullptr, nullptr, nullptr};
     float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
     float *d_mean_used = nullptr;    // the mean the latest finished solve sampled around (re-rolls)
     int *d_idx = nullptr;
@@ -80,6 +82,15 @@ struct bn_mppi {
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
     size_t resident_wgs = 1024;      // role-kernel workgroups the device holds at once (LDS- and wave-limited) x CUs
+    // overlapped launches (solve_n_overlapped): consecutive solves of one bn_mppi_solve_n_async call alternate between the handle's
+    // stream and `stream2`; device counters carry the dependency (SolveParams.flag_part / flag_tail)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long *d_flags = nullptr;      // [0..2] flag_part per slot, [3] flag_tail, then int err
+    unsigned long long pub[3] = {0, 0, 0};     // host mirror: what flag_part[slot] reaches once every launch issued so far has published
+    unsigned long long tails = 0;               // host mirror of flag_tail
+    bool prev_published = false;                // the latest solve counted itself into flag_part (latency kernel): its successor may overlap
+    bool overlap_used = false;                  // a wait could have expired since the last check of the device error word
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
@@ -159,8 +170,8 @@ int flush_tail(bn_mppi *h, float *out_copy = nullptr)
     if (!h->tail_pending) return BN_OK;
     bn::SolveParams p = h->p;
     p.out_copy = out_copy;
-    const int cur = (int)((h->solves - 1) & 1);
-    p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
+    const int cur = (int)((h->solves - 1) & 1), cur3 = (int)((h->solves - 1) % 3);
+    p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state = h->d_state_copy[cur3];
     if (h->ticket_mode) {
         p.tail_merged = 1;
         p.ustar_prev = h->d_ustar2[cur]; p.stats_prev = h->d_stats2[cur];
@@ -171,6 +182,8 @@ int flush_tail(bn_mppi *h, float *out_copy = nullptr)
         p.ep_index = h->ep_len - 1;
         p.env_z = h->ep_z ? h->ep_z + (size_t)(h->ep_len - 1) * p.B : nullptr;
     }
+    p.flag_tail = h->d_flags + 3;                      // every tail counts itself in (stream-ordered here: nothing to wait for)
+    h->tails += (unsigned long long)p.B;
     BN_HIP(bn::launch_finish(p, h->stream));
     h->tail_pending = false;
     return BN_OK;
@@ -318,7 +331,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     const bool want_wave = !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_ROLE_KERNEL | BN_FLAG_SAMPLED_SLIP)) && p.nblk <= 32 &&
                            ((cfg->flags & BN_FLAG_WAVE_KERNEL) || (size_t)p.B * (p.nblk + 1) > kWaveKernelMinWorkgroups);
     if (p.store_u || want_wave) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {
         alloc(&h->d_cost[q], B * K * 4);
         alloc(&h->d_part[q], B * (size_t)p.nblk * (2 + 2 * T) * 4);
         alloc(&h->d_state_copy[q], B * 3 * 4);
@@ -356,6 +369,13 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     h->lat_kernel = h->pipelined && !h->wave_kernel && !(cfg->flags & BN_FLAG_ROLE_KERNEL) && bn::lat_lds_bytes(p) > 0 &&
                     ((cfg->flags & BN_FLAG_LAT_KERNEL) || (size_t)p.B * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
     if (const char *e = std::getenv("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
+    alloc(&h->d_flags, 8 * sizeof(unsigned long long));
+    if (rc == BN_OK && h->lat_kernel) {
+        if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+            rc = fail(BN_ERR_HIP, "stream / event creation for overlapped launches failed");
+    }
     // (late allocations also go through `alloc`: a failure anywhere destroys the handle and everything it owns)
     if (p.slip_on) {
         alloc(&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4);
@@ -394,13 +414,17 @@ void bn_mppi_destroy(bn_mppi_t *h)
     DeviceGuard guard(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1],
-                    h->d_part[0], h->d_part[1], h->d_state_copy[0], h->d_state_copy[1], h->d_cost_out,
+    void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1], h->d_cost[2],
+                    h->d_part[0], h->d_part[1], h->d_part[2], h->d_state_copy[0], h->d_state_copy[1], h->d_state_copy[2], h->d_cost_out,
                     h->d_w, h->d_ustar /* d_xstar lives in the same block */, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
                     h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket, h->d_gpart, h->d_mean_used};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -490,7 +514,7 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
 
 // shard_rollout: the rollouts of a K-sharded solve only (bn_mppi_shard_rollout_async); the tail follows the exchange.
 static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise,
-                      bool shard_rollout)
+                      bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!states) return fail(BN_ERR_INVALID, "states is null");
@@ -566,10 +590,11 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     }
     h->last_eps = p.eps;
     h->last_mode = mode;
-    const int cur = (int)(h->solves & 1), prev = cur ^ 1;
+    const int cur = (int)(h->solves & 1), prev = cur ^ 1;                         // ticket-merge outputs: by parity
+    const int cur3 = (int)(h->solves % 3), prev3 = (int)((h->solves + 2) % 3);    // per-solve buffers: three slots
     p.solve = h->solves;
-    p.part = h->d_part[cur]; p.cost = h->d_cost[cur]; p.state_copy = h->d_state_copy[cur];
-    p.part_prev = h->d_part[prev]; p.cost_prev = h->d_cost[prev]; p.state_prev = h->d_state_copy[prev];
+    p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state_copy = h->d_state_copy[cur3];
+    p.part_prev = h->d_part[prev3]; p.cost_prev = h->d_cost[prev3]; p.state_prev = h->d_state_copy[prev3];
     if (h->pipelined && !shard_rollout) {
         // one launch: merge + tail of the previous solve ride along with this solve's rollouts
         p.have_prev = h->tail_pending ? 1 : 0;
@@ -584,15 +609,34 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         }
         p.wave_kernel = (h->wave_kernel && !h->in_episode) ? 1 : 0;
         p.lat_kernel = (h->lat_kernel && !h->in_episode) ? 1 : 0;      // device-side episodes advance the state in the role kernel's prologue
+        hipStream_t st = h->stream;
+        p.flag_tail = h->d_flags + 3;
+        if (p.have_prev) {                                             // the aux workgroups write the previous solve's tail
+            p.wait_tail = h->tails;                                    // ... after every tail before it
+            h->tails += (unsigned long long)p.B;
+        }
+        if (p.lat_kernel && overlap) {                                 // member of an overlapped batch: publishes, and waits if its predecessor published
+            p.flag_part = h->d_flags;
+            p.err = reinterpret_cast<int *>(h->d_flags + 4);
+            p.cur_slot = cur3; p.prev_slot = prev3;
+            p.wait_part = h->pub[prev3];
+            p.overlap = (h->prev_published && p.have_prev) ? 1 : 0;
+            if (p.overlap) { st = on_stream; h->overlap_used = true; }
+            h->pub[cur3] += (unsigned long long)p.B * p.nblk;
+            h->prev_published = true;
+        } else {
+            h->prev_published = false;
+        }
         // more workgroups than the role kernel keeps resident at once (4 per CU x 256 CUs): the aux workgroups run in freed slots
         p.aux_prio = (!p.wave_kernel && (size_t)p.B * (p.nblk + 1) > h->resident_wgs) ? 1 : 0;
         if (!p.wave_kernel && !p.store_u) p.U = nullptr;          // the buffer exists for the throughput kernel only
-        BN_HIP(bn::launch_rollout(p, mode, h->stream));
+        BN_HIP(bn::launch_rollout(p, mode, st));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
         h->tail_pending = true;
         return BN_OK;
     }
+    h->prev_published = false;
     p.have_prev = 0;
     p.mean_from_part = 0;
     p.tail_solve = p.solve;
@@ -674,7 +718,7 @@ int bn_mppi_shard_partials(bn_mppi_t *h, const float **partials_device, int32_t 
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->shard_pending) return fail(BN_ERR_STATE, "no sharded solve in flight");
-    const int cur = (int)((h->solves - 1) & 1);
+    const int cur = (int)((h->solves - 1) % 3);
     if (partials_device) *partials_device = h->d_part[cur];
     if (workgroups) *workgroups = h->p.nblk;
     if (floats_per_workgroup) *floats_per_workgroup = 2 + 2 * h->p.T;
@@ -688,7 +732,7 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
     if (!all_partials_device || total_workgroups < h->p.nblk) return fail(BN_ERR_INVALID, "need the partials of every shard");
     BN_BIND(h);
     bn::SolveParams p = h->p;
-    const int cur = (int)((h->solves - 1) & 1);
+    const int cur = (int)((h->solves - 1) % 3);
     p.solve = p.tail_solve = h->solves - 1;
     p.part = const_cast<float *>(all_partials_device);      // merged in shard order: identical on every rank
     p.nblk = total_workgroups;
@@ -703,11 +747,35 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
 {
     if (n < 0) return fail(BN_ERR_INVALID, "n must be >= 0");
     if (eps && (eps_ring < 1 || eps_stride < 0)) return fail(BN_ERR_INVALID, "eps_ring must be >= 1 and eps_stride >= 0");
-    for (int32_t i = 0; i < n; ++i) {
-        const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
-        if (int rc = bn_mppi_solve_async(h, states, states_where, e, noise)) return rc;
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    // Overlapped launches.  Solve i+1 needs only the softmin partials of solve i, yet in one stream it also waits for solve i's
+    // kernel to drain and for the dispatch of its own (~2.4 us of a 13 us step).  With the latency kernel consecutive solves
+    // alternate between the handle's stream and a second one: solve i+1 is dispatched while solve i runs, stages its window and
+    // draws its first noise, and then waits on a device counter for solve i's partials (published as device-scope stores by
+    // the workgroups themselves).  At most two launches are in flight (each stream serialises its own); per-solve buffers
+    // rotate over three slots so that what a launch overwrites was last read by a launch that has completed on its stream;
+    // the tails (aux workgroups) are ordered by a second counter.  Results are bit-identical to the one-stream chain.
+    const bool overlap = h->lat_kernel && h->stream2 && n >= 3 && states_where == BN_MEM_DEVICE && !h->in_episode &&
+                         noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending;
+    if (!overlap) {
+        for (int32_t i = 0; i < n; ++i) {
+            const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
+            if (int rc = bn_mppi_solve_async(h, states, states_where, e, noise)) return rc;
+        }
+        return BN_OK;
     }
-    return BN_OK;
+    BN_BIND(h);
+    BN_HIP(hipEventRecord(h->ev_fork, h->stream));                  // fork: the second stream starts behind everything enqueued so far
+    BN_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    int rc = BN_OK;
+    for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
+        const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
+        rc = solve_impl(h, states, states_where, e, noise, false, true, (i & 1) ? h->stream2 : h->stream);
+    }
+    hipError_t e1 = hipEventRecord(h->ev_join, h->stream2);         // join: the handle's stream continues behind both
+    hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join, 0);
+    if (rc == BN_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(BN_ERR_HIP, "joining the overlapped launches failed");
+    return rc;
 }
 
 int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *latent_std, bn_mem_kind where,
@@ -919,6 +987,15 @@ int bn_mppi_sync(bn_mppi_t *h)
     BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
+    if (h->overlap_used) {                             // a bounded device-side wait of an overlapped launch may have expired
+        int err = 0;
+        BN_HIP(hipMemcpy(&err, h->d_flags + 4, sizeof err, hipMemcpyDeviceToHost));
+        h->overlap_used = false;
+        if (err) {
+            BN_HIP(hipMemset(h->d_flags + 4, 0, sizeof(unsigned long long)));
+            return fail(BN_ERR_HIP, "an overlapped launch gave up waiting for its predecessor's partials: results are invalid");
+        }
+    }
     return BN_OK;
 }
 
@@ -951,7 +1028,7 @@ static int reroll_rows(bn_mppi_t *h, int32_t instance, const int *idx_device, in
     if (h->shard_pending) return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
     if (int rc = flush_tail(h)) return rc;
     bn::SolveParams p = h->p;
-    const int cur = (int)((h->solves - 1) & 1);
+    const int cur = (int)((h->solves - 1) % 3);
     p.solve = h->solves - 1;
     p.state = h->d_state_copy[cur];
     p.eps = h->last_eps;

@@ -318,6 +318,30 @@ __device__ __forceinline__ float wave_sum(float v)
 // partials inside one launch without a full L2 write-back / invalidate (see ticket_merge).
 __device__ __forceinline__ void store_agent(float *ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float load_agent(const float *ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool AGENT>
+__device__ __forceinline__ float ld(const float *ptr) { return AGENT ? load_agent(ptr) : *ptr; }
+template <bool AGENT>
+__device__ __forceinline__ void st(float *ptr, float v) { if (AGENT) store_agent(ptr, v); else *ptr = v; }
+
+// Overlapped launches: a counter another launch advances (device-scope atomics) reaches `need`.  ONE lane polls, with sc1 loads
+// and s_sleep in between; the caller puts a workgroup barrier behind it.  Bounded: a wait that does not end within ~2 s sets
+// *err and gives up -- a wrong result that bn_mppi_sync reports, never a hung GPU.
+__device__ __forceinline__ void wait_counter(const unsigned long long *ctr, unsigned long long need, int *err)
+{
+    for (int it = 0; it < (1 << 23); ++it) {
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Publish: every wave has seen its own sc1 stores acknowledged (vmcnt 0), the workgroup meets, one lane counts it in.
+__device__ __forceinline__ void publish_counter(unsigned long long *ctr, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // The workgroup's weighted control sums  sum_k e_k u_k[j]  (mppi.py:196-199, before the cross-workgroup merge) for the
 // 2T columns j of the LDS control tile (pitch kUPad).  One definition of the summation order for every rollout kernel,
@@ -500,10 +524,19 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 // The tail of one solve of instance b: U* (and the next mean), softmin statistics, normalised weights,
 // a stable copy of the costs, and the batch-1 rollout X* of U*.  NT threads (320 as the aux workgroup, 1024 stand-alone for large K).
 // LDS: [ window | ustar 2T | X* 3(T+1) | scale nblk | red 32 | group rows ceil(nblk/16) x (2+2T) if nblk > 64 | sampled mode: draws, (mean, std) window ]
-template <int GEO, bool LDSWIN, int NT, bool BIG = false>
+// AGENT: the launch overlaps its predecessor (other stream): wait for the counters first, read what the predecessor wrote with
+// device-scope loads, write what the successor's tail reads (mean) with device-scope stores.
+template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
 {
+    if (AGENT) {
+        if (threadIdx.x == 0) {
+            wait_counter(p.flag_part + p.prev_slot, p.wait_part, p.err);      // the solve whose tail this is has published everything
+            wait_counter(p.flag_tail, p.wait_tail, p.err);                   // and the tail before it has left the output buffers
+        }
+        __syncthreads();
+    }
     // p.tail_merged: U* and the softmin statistics of this solve were merged already (ticket merge of the sampled
     // kernel, which also wrote the next mean); they come from (ustar_prev, stats_prev).
     const int T = p.T, K = p.K, nblk = p.nblk, PS = 2 + 2 * p.T;
@@ -516,13 +549,13 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     const int tid = threadIdx.x;
     const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
     const float *part = part_all + (size_t)b * nblk * PS;
-    const float sx = state_all[b * 3 + 0], sy = state_all[b * 3 + 1], sth = state_all[b * 3 + 2];
+    const float sx = ld<AGENT>(state_all + b * 3 + 0), sy = ld<AGENT>(state_all + b * 3 + 1), sth = ld<AGENT>(state_all + b * 3 + 2);
     BN_STAMP(8);
 
     // the merge's loads go out before the window staging (which waits for the state): one memory round trip for both
     MergeLoads pre{};
     const bool pre_ok = !p.tail_merged && nblk <= 64;
-    if (pre_ok) pre = merge_issue(part, nblk, T, tid);
+    if (pre_ok) pre = merge_issue<AGENT>(part, nblk, T, tid);
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN && !p.slip_on) {
         w = window_origin<GEO>(p, sx, sy);
@@ -542,12 +575,12 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         S = p.stats_prev[b * 2 + 1];
         __syncthreads();
     } else {
-        merge_partials<NT, false, BIG>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
+        merge_partials<NT, AGENT, BIG>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
         for (int j = tid; j < 2 * T; j += NT) {
             p.ustar[(size_t)b * 2 * T + j] = us[j];
             if (p.out_copy) p.out_copy[(size_t)b * 2 * T + j] = us[j];
-            if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = p.mean[(size_t)b * 2 * T + j];   // what this solve sampled around
-            p.mean[(size_t)b * 2 * T + j] = us[j];            // _previous_action_seq = U*, no shift (mppi.py:217)
+            if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = ld<AGENT>(p.mean + (size_t)b * 2 * T + j);   // what this solve sampled around
+            st<AGENT>(p.mean + (size_t)b * 2 * T + j, us[j]);  // _previous_action_seq = U*, no shift (mppi.py:217)
         }
     }
     if (tid == 0) {
@@ -671,7 +704,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         float *wout = p.w + (size_t)b * K;
         float *cout = p.cost_out + (size_t)b * K;
         for (int k = tid - 64; k < K; k += NT - 64) {
-            const float ck = cost[k];
+            const float ck = ld<AGENT>(cost + k);
             cout[k] = ck;
             wout[k] = expf((-ck) / p.lambda_ - m) / S;
         }
@@ -697,6 +730,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             if (Xc) Xc[i] = v;
         }
     }
+    // one more tail done (counted per instance): what an overlapped successor's tail waits for before it takes the output buffers
+    if (p.flag_tail) publish_counter(p.flag_tail, tid);
 }
 
 // Ticket merge: every workgroup of instance b publishes its partials, takes a ticket, and the one that draws the

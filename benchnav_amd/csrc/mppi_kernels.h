@@ -85,6 +85,15 @@ struct SolveParams {
     const float *ustar_prev, *stats_prev;   // merge outputs of the solve whose tail this launch / the stand-alone tail writes
     int tail_merged;                   // the tail reads (ustar_prev, stats_prev) instead of merging `part`
     uint64_t tail_solve;               // index of the solve whose tail is written (its X* draws)
+    // ---- overlapped launches (solve_n_overlapped in mppi_capi.cpp): consecutive solves alternate between two streams, so a launch
+    // may start while its predecessor still runs; what stream order used to guarantee is carried by monotonic device counters ----
+    int overlap;                         // this launch must WAIT on the counters (its predecessor is on the other stream)
+    int cur_slot, prev_slot;             // slots (0..2) of this solve's and the previous solve's per-solve buffers
+    unsigned long long *flag_part;       // [3] rollout workgroups that have published their partials into slot j, ever
+    unsigned long long *flag_tail;       // tails (aux workgroups / finish kernels, one count per instance) completed, ever
+    unsigned long long wait_part;        // flag_part[prev_slot] value that means "the previous solve's partials and costs are all there"
+    unsigned long long wait_tail;        // flag_tail value that means "the tail before the one this launch carries is done"
+    int *err;                            // set non-zero when a bounded wait expired (reported by bn_mppi_sync)
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)

@@ -32,7 +32,7 @@ class NativeMPPI:
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
                  profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False, kernel: str = "auto",
-                 lean: bool = False):
+                 lean: bool = False, overlap: bool = True):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -61,6 +61,7 @@ class NativeMPPI:
                      | (0 if pipeline else _capi.BN_FLAG_NO_PIPELINE)
                      | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0)
                      | (_capi.BN_FLAG_LEAN if lean else 0)
+                     | (0 if overlap else _capi.BN_FLAG_NO_OVERLAP)
                      | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL, "lat": _capi.BN_FLAG_LAT_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances

@@ -76,6 +76,8 @@ enum {
     BN_FLAG_NO_PIPELINE = 1u << 5,     /* always two launches per solve (rollout, finish); see bn_mppi_solve_async */
     BN_FLAG_WAVE_KERNEL = 1u << 7,     /* always use the one-wave-per-64-rollouts throughput kernel (default: chosen by launch size) */
     BN_FLAG_ROLE_KERNEL = 1u << 8,     /* always use the five-wave role-split latency kernel */
+    BN_FLAG_NO_OVERLAP = 1u << 11,     /* bn_mppi_solve_n_async keeps all its launches on the handle's stream (default: with the latency
+                                          kernel consecutive solves alternate between two streams and overlap, see there) */
     BN_FLAG_LAT_KERNEL = 1u << 10,     /* always use the barrier-free latency variant of the role kernel when it fits (default: when the
                                           launch leaves every workgroup a CU to itself) */
     BN_FLAG_LEAN = 1u << 9,            /* lean mode: _state_seq_batch (mppi.py:119-125) is not materialised -- 70 % of a solve's
@@ -175,8 +177,12 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
 int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise,
                           float *out_device);
 /* n dependent solves enqueued from one call (the warm start chains them on the device; the state is
- * re-read from `states` by every solve, so a device-resident state may be advanced in between by
- * other work on the same stream).  Noise block i is eps + (i % eps_ring) * eps_stride floats. */
+ * re-read from `states` by every solve).  Noise block i is eps + (i % eps_ring) * eps_stride floats.
+ * With the latency kernel (small launches) and n >= 3 the solves alternate between the handle's stream and an
+ * internal one and overlap: solve i+1 is dispatched while solve i runs and waits on a device counter for its
+ * partials instead of for its kernel's end; the call forks from and joins back into the handle's stream, so the
+ * caller sees ordinary stream order, and the results are bit-identical (BN_FLAG_NO_OVERLAP turns it off).
+ * Device-side waits are bounded; bn_mppi_sync reports BN_ERR_HIP if one expired. */
 int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
 

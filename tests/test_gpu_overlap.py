@@ -1,0 +1,87 @@
+"""GPU: overlapped launches of bn_mppi_solve_n_async (consecutive solves alternate between two streams; device counters
+carry the dependency; per-solve buffers rotate over three slots).  Bar: bit-identical to the one-stream chain -- every output
+of the last solve, and through it (warm start) every solve before it -- for every noise source, lean mode, several
+instances, and call sequences that mix overlapped batches with single solves and getters."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = 256
+
+
+def _make(K, T, B, insts, overlap, **kw):
+    from benchnav_amd import NativeMPPI
+    pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, seed=5, overlap=overlap, **kw)
+    for b, it in enumerate(insts):
+        pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
+    return pl
+
+
+def _outputs(pl, B, T):
+    import torch
+    from benchnav_amd import _capi
+    from benchnav_amd.mppi import _DevArray
+    pl.sync()
+    xs = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_XSTAR)[0], (B, T + 1, 3)), device="cuda").cpu().numpy()
+    us = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_USTAR)[0], (B, T, 2)), device="cuda").cpu().numpy()
+    return [(pl.states(b), pl.costs(b), pl.weights(b), pl.get_mean(b), xs[b].copy(), us[b].copy()) for b in range(B)]
+
+
+@pytest.mark.parametrize("K,T,B,noise,lean,n", [(1024, 50, 1, "philox", False, 40), (1024, 50, 3, "philox", True, 25), (1000, 33, 2, "kt2", False, 12),
+                                                (2048, 50, 1, "t2k", False, 9), (130, 7, 5, "philox", False, 60), (64, 1, 1, "philox", False, 30),
+                                                (1024, 50, 1, "philox", False, 3)],
+                         ids=["c2", "c2-B3-lean", "ragged-kt2", "K2048-t2k", "small-B5", "T1", "n3"])
+def test_overlapped_chain_equals_one_stream_chain(K, T, B, noise, lean, n):
+    import torch
+    from benchnav_amd import _capi, synth
+    insts = [synth.make_instance(G, seed=70 + b, jitter=True) for b in range(B)]
+    st = torch.stack([it.start for it in insts]).cuda()
+    ring = min(n, 4)
+    eps = np.random.default_rng(6).standard_normal((ring, B, K, T, 2)).astype(np.float32)
+    if noise == "kt2":
+        ed, kind = torch.from_numpy(eps).cuda(), _capi.BN_NOISE_DEVICE_KT2
+    elif noise == "t2k":
+        ed, kind = torch.from_numpy(np.ascontiguousarray(eps.transpose(0, 1, 3, 4, 2))).cuda(), _capi.BN_NOISE_DEVICE_T2K
+    else:
+        ed, kind = None, _capi.BN_NOISE_PHILOX
+    torch.cuda.synchronize()
+    res = {}
+    for overlap in (False, True):
+        with _make(K, T, B, insts, overlap, store_controls=not lean, lean=lean, kernel="lat") as pl:
+            if ed is None:
+                pl.solve_n_async_device(n, st.data_ptr())
+            else:
+                pl.solve_n_async_device(n, st.data_ptr(), ed.data_ptr(), kind, ring, eps[0].size)
+            res[overlap] = _outputs(pl, B, T)
+    for b in range(B):
+        for j, (a_, b_) in enumerate(zip(res[True][b], res[False][b])):
+            assert np.array_equal(a_, b_), (b, j)
+
+
+def test_mixed_call_sequences_and_a_long_chain():
+    """Batches of different lengths, single solves, getters and a changed state in between; then 3000 solves in one call."""
+    import torch
+    from benchnav_amd import synth
+    K, T = 512, 20
+    inst = synth.make_instance(G, seed=3)
+    st = inst.start.cuda()
+    st2 = (inst.start + torch.tensor([0.3, -0.2, 0.1])).cuda()
+    torch.cuda.synchronize()
+    res = {}
+    for overlap in (False, True):
+        with _make(K, T, 1, [inst], overlap, kernel="lat") as pl:
+            seq = []
+            pl.solve_n_async_device(7, st.data_ptr())
+            seq.append(pl.get_mean(0))                       # getter: flushes the pending tail
+            pl.solve_async_device(st2.data_ptr())            # a single solve between batches (one stream)
+            pl.solve_n_async_device(4, st2.data_ptr())
+            seq.append(pl.weights(0))
+            pl.solve_n_async_device(3, st.data_ptr())
+            pl.solve_n_async_device(2, st.data_ptr())        # too short to overlap
+            seq.append(pl.costs(0))
+            pl.solve_n_async_device(3000, st.data_ptr())
+            seq.extend(_outputs(pl, 1, T)[0])
+            assert pl.solve_count() == 7 + 1 + 4 + 3 + 2 + 3000
+            res[overlap] = seq
+    for j, (a_, b_) in enumerate(zip(res[True], res[False])):
+        assert np.array_equal(a_, b_), j
