@@ -22,8 +22,10 @@ K of 20 is not a 0.3 ms sample; `ms_per_step` / `value` are the MEDIAN repeat, t
 
 Extra objects on the line:
   roofline      dominant kernel (rollout) against the HBM roofline: algorithmic bytes per launch over the kernel's mean
-                launch-to-launch duration, from a HIP event pair around the K launches of the SAME timed region on the
-                launch stream (so kernel_ms <= ms_per_step by construction)
+                launch-to-launch duration, from a HIP event pair on the launch stream around the same K launches on the same
+                handle right after the timed repeats (the timed region itself holds nothing but the solves)
+  no_overlap    the headline with every launch on one stream: the configuration whose per-kernel duration rocprofv3 reports
+                directly (by default consecutive dependent solves overlap on two streams, bn_mppi_solve_n_async)
   cpu_baseline  the PyTorch-CPU port of the reference (oracle/torch_port.py) timed on this host (N = 1 only)
   batched       64 instances per launch (config 4's per-node batch on one GPU): the regime where the HBM roofline is
                 meaningful; with its lean-mode line (no trajectory dump) beside the full-API one
@@ -58,6 +60,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="keep every launch on one stream (BN_FLAG_NO_OVERLAP): the configuration whose per-kernel duration rocprofv3 "
+                         "reports directly; by default consecutive dependent solves overlap on two streams")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher check without a GPU: spawn the ranks, rendezvous, gather, print who took part; no planning")
@@ -154,29 +159,33 @@ def main():
     stream = torch.cuda.current_stream()
 
     def make_planner(inst, B=1, **kw):
+        kw.setdefault("overlap", not a.no_overlap)
         pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=dev,
                         stream=stream.cuda_stream, **kw)
         pl.set_map(inst.risk.numpy())
         pl.set_goal(inst.goal.numpy())
         return pl
 
-    def timed_solves(pl, state_dev, eps_ring, kind, steps, sync_):
+    def timed_solves(pl, state_dev, eps_ring, kind, steps, sync_, events=True):
         """Enqueue `steps` dependent solves (software-pipelined: one launch each), then the tail of the last one.
         Returns (wall seconds between the two syncs, milliseconds between HIP events placed on the launch stream before
-        the first and after the last launch).  Every solve's U*, X* and weights are written."""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        the first and after the last launch, or None without `events`).  Every solve's U*, X* and weights are written."""
+        if events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         sync_()
         t0 = time.perf_counter()
-        e0.record(stream)
+        if events:
+            e0.record(stream)
         if eps_ring is None:
             pl.solve_n_async_device(steps, state_dev.data_ptr())
         else:                                            # eps_ring: one contiguous tensor (ring, ...), cycled per solve
             pl.solve_n_async_device(steps, state_dev.data_ptr(), eps_ring.data_ptr(), kind, eps_ring.shape[0], eps_ring[0].numel())
-        e1.record(stream)
+        if events:
+            e1.record(stream)
         pl.flush()
         sync_()
         wall = time.perf_counter() - t0
-        return wall, e0.elapsed_time(e1)
+        return wall, (e0.elapsed_time(e1) if events else None)
 
     def settle(make, state_dev, eps_ring, kind, warmup, tries=3):
         """Untimed: build the planner, run the warm-up steps, and make sure the queue is not in the rare slow-dispatch
@@ -197,11 +206,10 @@ def main():
         return make()
 
     def repeated(pl, state_dev, eps_ring, kind, steps, sync_, repeats):
-        walls, evs = [], []
-        for _ in range(repeats):
-            w, e = timed_solves(pl, state_dev, eps_ring, kind, steps, sync_)
-            walls.append(w)
-            evs.append(e)
+        """The contract's timed region, `repeats` times: nothing inside it but the K solves and the last tail.  The kernel's
+        launch-to-launch time comes from the same handle right afterwards: the same K launches between two HIP events."""
+        walls = [timed_solves(pl, state_dev, eps_ring, kind, steps, sync_, events=False)[0] for _ in range(repeats)]
+        evs = [timed_solves(pl, state_dev, eps_ring, kind, steps, torch.cuda.synchronize)[1] for _ in range(min(repeats, 20))]
         return walls, evs
 
     inst = synth.make_instance(G, seed=rank, resolution=RES)       # independent map seed per rank
@@ -244,7 +252,7 @@ def main():
 
     out = None
     if rank == 0:
-        kernel_ms = evs[r_med] / a.steps                            # same handle, same repeat as ms_per_step
+        kernel_ms = statistics.median(evs) / a.steps               # same handle, the same K launches, right after the timed repeats
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per launch, see profiles/README.md
@@ -286,17 +294,34 @@ def main():
                          "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "kernel": "bn::rollout_kernel (5 role-specialised waves per 64 rollouts; in the pipelined "
                                    "mode it also carries the previous solve's merge + tail workgroup)",
-                         "kernel_ms": kernel_ms, "kernel_ms_source": "HIP event pair on the launch stream around the K launches of the "
-                                                                     "median repeat (launch-to-launch mean)",
+                         "kernel_ms": kernel_ms,
+                         "kernel_ms_source": "HIP event pair on the launch stream around the same K launches on the same handle, right after "
+                                             "the timed repeats (median; launch-to-launch mean).  With overlapped launches (default) two kernels "
+                                             "are in flight and each one's own duration, as rocprofv3 lists it, includes its wait for the "
+                                             "predecessor's partials (about twice this figure); `no_overlap` below is the one-stream "
+                                             "configuration whose per-kernel duration rocprofv3 reports directly",
+                         "overlapped_launches": not a.no_overlap,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": a.steps,
                          "note": "single-instance solve = 16 workgroups x a 50-step serial chain (~5.2 us of dependent instructions): "
                                  "latency-bound; at 0.9 MB per solve one launch boundary (~1.4 us) alone caps a launch-per-solve design "
                                  "at ~7 % of HBM peak and the chain at ~2 %; the batched object is the HBM-relevant regime (DESIGN.md 6)"},
         }
+        if not a.no_overlap:
+            pn = make_planner(inst, overlap=False)
+            timed_solves(pn, state_dev, eps_ring, kind, max(a.warmup, 50), torch.cuda.synchronize)
+            w_n, e_n = timed_solves(pn, state_dev, eps_ring, kind, max(a.steps, 1000), torch.cuda.synchronize)
+            pn.close()
+            n_n = max(a.steps, 1000)
+            out["no_overlap"] = {"value": n_n / w_n, "unit": "solves/s", "ms_per_step": w_n / n_n * 1e3, "kernel_ms": e_n / n_n, "steps": n_n,
+                                 "roofline_frac": alg_bytes / (e_n / n_n * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "BN_FLAG_NO_OVERLAP: every launch on the handle's stream, one kernel in flight"}
         if shared_gpu or backend != "nccl":
             out["rehearsal"] = f"ranks shared {ndev} GPU(s), backend {backend}: not a scaling measurement"
         if sustained:
             out["sustained"] = sustained
+            out["sustained"]["note"] = ("the contract's K steps are one short timed region: launch latency of the first solve, the last solve's tail "
+                                        "kernel and the synchronisation are paid once per region; this is the same handle over 3000 steps")
+            out["fixed_overhead_us_per_timed_region"] = (med / a.steps - sustained["ms_per_step"] * 1e-3) * a.steps * 1e6
 
     if extras:
         def leg(pl_, st_, ring_, n_):

@@ -11,6 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --no-cpu-baseline --steps 1000 --warmup 100 > $OUT/${TAG}_bench_profiled.json 2> $OUT/trace.err
 DB=$(find $OUT/trace -name "*.db" | head -1)
 [ -n "$DB" ] && python $REPO/tools/rocpd_summary.py stats $DB $OUT/${TAG}_kernel_stats.csv || tail -5 $OUT/trace.err
+# the same command with every launch on one stream: the per-kernel durations here are what bench.py's no_overlap.kernel_ms must agree with
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace1 -o t -- python $REPO/bench.py --no-cpu-baseline --no-overlap --steps 1000 --warmup 100 > $OUT/${TAG}_bench_profiled_no_overlap.json 2> $OUT/trace1.err
+DB=$(find $OUT/trace1 -name "*.db" | head -1)
+[ -n "$DB" ] && python $REPO/tools/rocpd_summary.py stats $DB $OUT/${TAG}_kernel_stats_no_overlap.csv || tail -5 $OUT/trace1.err
 for c in B1 B1_lean B64 B64_lean B256 B256_lean sampled c5; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     k=$( [ $ctr = FETCH_SIZE ] && echo fetch || echo write )
@@ -29,5 +33,5 @@ python tools/traffic_from_pmc.py $OUT/pmc $TAG $COMMIT
 timeout 600 python bench.py --steps 3000 --warmup 200 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_args.json 2>> $OUT/bench.err
 tail -c 400 $OUT/${TAG}_bench.json
-find $OUT -name "*.db" -delete; rm -rf $OUT/trace $OUT/p_* $OUT/sqa_* $OUT/sqb_*
+find $OUT -name "*.db" -delete; rm -rf $OUT/trace $OUT/trace1 $OUT/p_* $OUT/sqa_* $OUT/sqb_*
 du -sh $OUT
