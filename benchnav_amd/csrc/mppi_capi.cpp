@@ -87,6 +87,12 @@ struct bn_mppi {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long *d_flags = nullptr;      // [0..2] flag_part per slot, [3] flag_tail, then int err
+    unsigned long long *d_gran[3] = {nullptr, nullptr, nullptr};   // granule copies of the partial rows per slot (K <= 1024, 2T <= 320)
+    // Second trajectory / control buffers for overlapped batches.  Two launches in flight must not write the same addresses: whose
+    // dirty L2 lines reach memory last is decided by which KERNEL ends last, and a straggling aux workgroup can make the earlier
+    // solve's kernel the later one to end (seen once per cold start: X / U of the last solve partly overwritten by its
+    // predecessor's).  Solves of a batch alternate between the two buffers such that the LAST one writes the exposed buffer.
+    float *d_X2 = nullptr, *d_U2 = nullptr;
     unsigned long long pub[3] = {0, 0, 0};     // host mirror: what flag_part[slot] reaches once every launch issued so far has published
     unsigned long long tails = 0;               // host mirror of flag_tail
     bool prev_published = false;                // the latest solve counted itself into flag_part (latency kernel): its successor may overlap
@@ -370,6 +376,12 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
                     ((cfg->flags & BN_FLAG_LAT_KERNEL) || (size_t)p.B * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
     if (const char *e = std::getenv("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
     alloc(&h->d_flags, 8 * sizeof(unsigned long long));
+    if (h->lat_kernel && p.nblk <= 16 && 2 * p.T <= bn::kRolloutThreads && !std::getenv("BN_NO_GRANULES"))
+        for (int q = 0; q < 3; ++q) alloc(&h->d_gran[q], B * (size_t)p.nblk * (2 + 2 * T) * sizeof(unsigned long long));
+    if (h->lat_kernel && !(cfg->flags & BN_FLAG_NO_OVERLAP)) {
+        if (h->d_X) alloc(&h->d_X2, B * (T + 1) * 3 * (size_t)p.Kp * 4);
+        if (h->d_U) alloc(&h->d_U2, B * T * 2 * (size_t)p.Kp * 4);
+    }
     if (rc == BN_OK && h->lat_kernel) {
         if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -422,6 +434,10 @@ void bn_mppi_destroy(bn_mppi_t *h)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    for (int q = 0; q < 3; ++q)
+        if (h->d_gran[q]) (void)hipFree(h->d_gran[q]);
+    if (h->d_X2) (void)hipFree(h->d_X2);
+    if (h->d_U2) (void)hipFree(h->d_U2);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -514,7 +530,7 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
 
 // shard_rollout: the rollouts of a K-sharded solve only (bn_mppi_shard_rollout_async); the tail follows the exchange.
 static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise,
-                      bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr)
+                      bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr, bool alt_buffers = false)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!states) return fail(BN_ERR_INVALID, "states is null");
@@ -620,7 +636,13 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             p.err = reinterpret_cast<int *>(h->d_flags + 4);
             p.cur_slot = cur3; p.prev_slot = prev3;
             p.wait_part = h->pub[prev3];
+            p.gran = h->d_gran[cur3];
+            if (alt_buffers) {                                         // this solve's trajectories / controls go to the second buffers
+                if (h->d_X2) p.X = h->d_X2;
+                if (h->d_U2 && p.U) p.U = h->d_U2;
+            }
             p.overlap = (h->prev_published && p.have_prev) ? 1 : 0;
+            p.gran_prev = p.overlap ? h->d_gran[prev3] : nullptr;
             if (p.overlap) { st = on_stream; h->overlap_used = true; }
             h->pub[cur3] += (unsigned long long)p.B * p.nblk;
             h->prev_published = true;
@@ -755,7 +777,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // the workgroups themselves).  At most two launches are in flight (each stream serialises its own); per-solve buffers
     // rotate over three slots so that what a launch overwrites was last read by a launch that has completed on its stream;
     // the tails (aux workgroups) are ordered by a second counter.  Results are bit-identical to the one-stream chain.
-    const bool overlap = h->lat_kernel && h->stream2 && n >= 3 && states_where == BN_MEM_DEVICE && !h->in_episode &&
+    const bool overlap = h->lat_kernel && h->stream2 && (h->d_X2 || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE && !h->in_episode &&
                          noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending;
     if (!overlap) {
         for (int32_t i = 0; i < n; ++i) {
@@ -770,7 +792,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     int rc = BN_OK;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
-        rc = solve_impl(h, states, states_where, e, noise, false, true, (i & 1) ? h->stream2 : h->stream);
+        rc = solve_impl(h, states, states_where, e, noise, false, true, (i & 1) ? h->stream2 : h->stream, ((n - 1 - i) & 1) != 0);
     }
     hipError_t e1 = hipEventRecord(h->ev_join, h->stream2);         // join: the handle's stream continues behind both
     hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join, 0);

@@ -343,6 +343,20 @@ __device__ __forceinline__ void publish_counter(unsigned long long *ctr, int tid
     if (tid == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Granules: an 8-byte {value, tag} pair written by ONE device-scope store, so a reader that sees the tag sees the value.
+// The partial rows an overlapped successor's prologue needs are published this way as well (tag = producing solve's
+// index + 1): it can poll the rows themselves -- one memory round trip -- instead of a counter and then the rows.
+__device__ __forceinline__ void store_granule(unsigned long long *ptr, float v, uint32_t tag)
+{
+    __hip_atomic_store(ptr, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_granule(const unsigned long long *ptr, uint32_t tag, bool &ok)
+{
+    const unsigned long long g = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = ok && (uint32_t)(g >> 32) == tag;
+    return __uint_as_float((uint32_t)g);
+}
+
 // The workgroup's weighted control sums  sum_k e_k u_k[j]  (mppi.py:196-199, before the cross-workgroup merge) for the
 // 2T columns j of the LDS control tile (pitch kUPad).  One definition of the summation order for every rollout kernel,
 // so that all of them produce the same bits: the 64 rollouts in four quarters of 16, each summed in rollout order with
@@ -350,7 +364,8 @@ __device__ __forceinline__ void publish_counter(unsigned long long *ctr, int tid
 // over NT threads; 64 sequential fma per column on a quarter of the threads was 0.55 us of a 13 us solve) and the
 // combination is two DPP quad permutes.  NT and the item count are multiples of 4: a quad is active as a whole.
 template <int NT, bool AGENT>
-__device__ __forceinline__ void column_sums(const float *Ul, const float *el, int T, int tid, float *part)
+__device__ __forceinline__ void column_sums(const float *Ul, const float *el, int T, int tid, float *part,
+                                            unsigned long long *grow = nullptr, uint32_t tag = 0)
 {
     for (int it = tid; it < 8 * T; it += NT) {
         const int j = it >> 2, r = it & 3;
@@ -362,7 +377,10 @@ __device__ __forceinline__ void column_sums(const float *Ul, const float *el, in
                      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
                      : "+v"(acc));
-        if (r == 0) { if (AGENT) store_agent(part + 2 + j, acc); else part[2 + j] = acc; }
+        if (r == 0) {
+            if (grow) store_granule(grow + 2 + j, acc, tag);           // first: what the successor's prologue polls
+            if (AGENT) store_agent(part + 2 + j, acc); else part[2 + j] = acc;
+        }
     }
 }
 
@@ -407,6 +425,27 @@ __device__ __forceinline__ MergeLoads merge_issue(const float *__restrict__ part
     L.si = has ? BN_PLD((size_t)lane * PS + 1) : 0.0f;
     return L;
 #undef BN_PLD
+}
+
+// The same loads from the granule copy of the rows (nblk <= kMergePrefetch), each checked against the producing solve's tag:
+// `ok` stays true only if every granule this thread needs carried it.
+__device__ __forceinline__ MergeLoads merge_issue_granules(const unsigned long long *__restrict__ grows, int nblk, int T, int tid, uint32_t tag, bool &ok)
+{
+    const int PS = 2 + 2 * T;
+    const int lane = tid & 63;
+    MergeLoads L;
+    L.j = tid < 2 * T ? tid : 0;
+    ok = true;
+#pragma unroll
+    for (int i = 0; i < kMergePrefetch; ++i) L.v[i] = load_granule(grows + (size_t)min(i, nblk - 1) * PS + 2 + L.j, tag, ok);
+    const bool has = lane < nblk;
+    bool ok2 = true;
+    const float mi = load_granule(grows + (size_t)min(lane, nblk - 1) * PS, tag, ok2);
+    const float si = load_granule(grows + (size_t)min(lane, nblk - 1) * PS + 1, tag, ok2);
+    ok = ok && ok2;
+    L.mi = has ? mi : -INFINITY;
+    L.si = has ? si : 0.0f;
+    return L;
 }
 
 // Two-level merge for more than 64 partial rows (K > 4096): rows are first merged in groups of kGroupRows

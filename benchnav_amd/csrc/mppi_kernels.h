@@ -94,6 +94,8 @@ struct SolveParams {
     unsigned long long wait_part;        // flag_part[prev_slot] value that means "the previous solve's partials and costs are all there"
     unsigned long long wait_tail;        // flag_tail value that means "the tail before the one this launch carries is done"
     int *err;                            // set non-zero when a bounded wait expired (reported by bn_mppi_sync)
+    unsigned long long *gran, *gran_prev;   // (B, nblk, 2+2T) granule copies {value, tag} of this / the previous solve's partial rows
+                                            // (overlapped batches with K <= 1024: the successor's prologue polls the rows themselves)
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)

@@ -24,7 +24,8 @@ def _outputs(pl, B, T):
     pl.sync()
     xs = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_XSTAR)[0], (B, T + 1, 3)), device="cuda").cpu().numpy()
     us = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_USTAR)[0], (B, T, 2)), device="cuda").cpu().numpy()
-    return [(pl.states(b), pl.costs(b), pl.weights(b), pl.get_mean(b), xs[b].copy(), us[b].copy()) for b in range(B)]
+    return [(pl.states(b), pl.costs(b), pl.weights(b), pl.get_mean(b), xs[b].copy(), us[b].copy())
+            + ((pl.controls(b),) if pl.store_controls else ()) for b in range(B)]
 
 
 @pytest.mark.parametrize("K,T,B,noise,lean,n", [(1024, 50, 1, "philox", False, 40), (1024, 50, 3, "philox", True, 25), (1000, 33, 2, "kt2", False, 12),
@@ -56,6 +57,32 @@ def test_overlapped_chain_equals_one_stream_chain(K, T, B, noise, lean, n):
     for b in range(B):
         for j, (a_, b_) in enumerate(zip(res[True][b], res[False][b])):
             assert np.array_equal(a_, b_), (b, j)
+
+
+def test_fresh_handles_keep_the_last_solves_trajectories():
+    """Two launches in flight never write the same trajectory / control addresses (the batch alternates between two buffers and
+    ends on the exposed one).  A cold handle is where a late-ending earlier kernel used to overwrite rows of the last solve:
+    repeat short batches on fresh handles, odd and even lengths, and compare the dumps with the one-stream chain."""
+    import torch
+    from benchnav_amd import _capi, synth
+    K, T, B = 1000, 33, 2
+    insts = [synth.make_instance(G, seed=30 + b, jitter=True) for b in range(B)]
+    st = torch.stack([it.start for it in insts]).cuda()
+    eps = np.random.default_rng(4).standard_normal((6, B, K, T, 2)).astype(np.float32)
+    ed = torch.from_numpy(eps).cuda()
+    torch.cuda.synchronize()
+    for n in (5, 6):
+        want = None
+        for rep in range(7):
+            with _make(K, T, B, insts, rep > 0, store_controls=True, kernel="lat") as pl:
+                pl.solve_n_async_device(n, st.data_ptr(), ed.data_ptr(), _capi.BN_NOISE_DEVICE_KT2, n, eps[0].size)
+                got = _outputs(pl, B, T)
+            if want is None:
+                want = got
+                continue
+            for b in range(B):
+                for j, (a_, b_) in enumerate(zip(got[b], want[b])):
+                    assert np.array_equal(a_, b_), (n, rep, b, j)
 
 
 def test_mixed_call_sequences_and_a_long_chain():
