@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -19,7 +21,7 @@
 namespace {
 
 constexpr int kProfGroup = 10;
-constexpr size_t kWaveKernelMinWorkgroups = 1536;   // measured crossover (tools/wave_vs_role.py): ~96 instances of K=1024
+constexpr size_t kWaveKernelMinWorkgroups = 1900;   // measured crossover (tools/batched_rate.py, BN_KERNEL=role|wave): between 96 and 128 instances of K=1024, overlapped or not
 thread_local std::string g_last_error;
 
 int fail(int code, const char *fmt, ...)
@@ -49,6 +51,16 @@ bool is_pow2_float(float v)
     return v > 0.0f && std::isfinite(v) && std::frexp(v, &ex) == 0.5f;
 }
 
+// One overlapped batch per device at a time.  Workgroups of an overlapped launch hold their slots while they wait for their
+// predecessor; two handles doing that at once can starve each other's predecessors of slots until the bounded waits expire
+// (8 handles x 8 instances: seen).  A handle overlaps only while no OTHER handle's overlapped batch is still in flight on its
+// device (`ev_done` of the owner not yet reached); otherwise this batch runs in one stream, which is always safe.
+std::mutex g_overlap_mu;
+std::map<int, bn_mppi *> g_overlap_owner;   // device -> the handle whose overlapped batch was enqueued last
+
+constexpr int kMaxStreams = 3;            // launches of one overlapped batch in flight at most
+constexpr int kSlots = kMaxStreams + 1;   // per-solve buffer slots (see bn_mppi::d_cost)
+
 }  // namespace
 
 struct bn_mppi {
@@ -68,9 +80,9 @@ struct bn_mppi {
     // device buffers
     float *d_map = nullptr, *d_state = nullptr, *d_goal = nullptr, *d_mean = nullptr, *d_eps = nullptr;
     float *d_X = nullptr, *d_U = nullptr, *d_w = nullptr, *d_cost_out = nullptr;
-    // per-solve buffers rotate over THREE slots (solve i uses slot i % 3): with overlapped launches (see solve_n_overlapped)
-    // solve i+2 may start while solve i+1's aux workgroup still reads solve i's slot
-    float *d_cost[3] = {nullptr, nullptr, nullptr}, *d_part[3] = {nullptr, nullptr, nullptr}, *d_state_copy[3] = {nullptr, nullptr, nullptr};
+    // per-solve buffers rotate over kSlots slots (solve i uses slot i % kSlots): with S launches in flight (see bn_mppi_solve_n_async)
+    // solve i+S may start while solve i+1 -- its merge, its aux workgroup -- still reads solve i's slot: S + 1 slots are enough
+    float *d_cost[kSlots] = {}, *d_part[kSlots] = {}, *d_state_copy[kSlots] = {};
     float *d_ustar = nullptr, *d_xstar = nullptr, *d_stats = nullptr, *d_scratch = nullptr;
     float *d_mean_used = nullptr;    // the mean the latest finished solve sampled around (re-rolls)
     int *d_idx = nullptr;
@@ -82,19 +94,21 @@ struct bn_mppi {
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
     size_t resident_wgs = 1024;      // role-kernel workgroups the device holds at once (LDS- and wave-limited) x CUs
-    // overlapped launches (solve_n_overlapped): consecutive solves of one bn_mppi_solve_n_async call alternate between the handle's
-    // stream and `stream2`; device counters carry the dependency (SolveParams.flag_part / flag_tail)
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    unsigned long long *d_flags = nullptr;      // [0..2] flag_part per slot, [3] flag_tail, then int err
-    unsigned long long *d_gran[3] = {nullptr, nullptr, nullptr};   // granule copies of the partial rows per slot (K <= 1024, 2T <= 320)
+    // overlapped launches: consecutive solves of one bn_mppi_solve_n_async call go round the handle's stream and n_streams - 1
+    // extra ones; device counters carry the dependency (SolveParams.flag_part / flag_tail)
+    int n_streams = 1;
+    hipStream_t xstream[kMaxStreams - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams - 1] = {}, ev_done = nullptr;   // ev_done: behind everything of the latest overlapped batch
+    unsigned long long *d_flags = nullptr;      // [kSlots][B] flag_part per slot and instance, [B] flag_tail per instance, then int err
+    bool role_overlap = false;                  // the role kernel's launches of a batch may overlap too (see bn_mppi_solve_n_async)
+    unsigned long long *d_gran[kSlots] = {};   // granule copies of the partial rows per slot (K <= 1024, 2T <= 320)
     // Second trajectory / control buffers for overlapped batches.  Two launches in flight must not write the same addresses: whose
     // dirty L2 lines reach memory last is decided by which KERNEL ends last, and a straggling aux workgroup can make the earlier
     // solve's kernel the later one to end (seen once per cold start: X / U of the last solve partly overwritten by its
-    // predecessor's).  Solves of a batch alternate between the two buffers such that the LAST one writes the exposed buffer.
-    float *d_X2 = nullptr, *d_U2 = nullptr;
-    unsigned long long pub[3] = {0, 0, 0};     // host mirror: what flag_part[slot] reaches once every launch issued so far has published
-    unsigned long long tails = 0;               // host mirror of flag_tail
+    // predecessor's).  Solves of a batch go round n_streams buffers such that the LAST one writes the exposed buffer.
+    float *d_Xalt[kMaxStreams - 1] = {}, *d_Ualt[kMaxStreams - 1] = {};
+    unsigned long long pub[kSlots] = {};     // host mirror: what flag_part[slot][b] reaches once every launch issued so far has published
+    unsigned long long tails = 0;               // host mirror of flag_tail[b]
     bool prev_published = false;                // the latest solve counted itself into flag_part (latency kernel): its successor may overlap
     bool overlap_used = false;                  // a wait could have expired since the last check of the device error word
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
@@ -176,7 +190,7 @@ int flush_tail(bn_mppi *h, float *out_copy = nullptr)
     if (!h->tail_pending) return BN_OK;
     bn::SolveParams p = h->p;
     p.out_copy = out_copy;
-    const int cur = (int)((h->solves - 1) & 1), cur3 = (int)((h->solves - 1) % 3);
+    const int cur = (int)((h->solves - 1) & 1), cur3 = (int)((h->solves - 1) % kSlots);
     p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state = h->d_state_copy[cur3];
     if (h->ticket_mode) {
         p.tail_merged = 1;
@@ -188,8 +202,8 @@ int flush_tail(bn_mppi *h, float *out_copy = nullptr)
         p.ep_index = h->ep_len - 1;
         p.env_z = h->ep_z ? h->ep_z + (size_t)(h->ep_len - 1) * p.B : nullptr;
     }
-    p.flag_tail = h->d_flags + 3;                      // every tail counts itself in (stream-ordered here: nothing to wait for)
-    h->tails += (unsigned long long)p.B;
+    p.flag_tail = h->d_flags + kSlots * (size_t)p.B * bn::kFlagStride;        // every tail counts itself in (stream-ordered here: nothing to wait for)
+    h->tails += 1;
     BN_HIP(bn::launch_finish(p, h->stream));
     h->tail_pending = false;
     return BN_OK;
@@ -337,7 +351,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     const bool want_wave = !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_ROLE_KERNEL | BN_FLAG_SAMPLED_SLIP)) && p.nblk <= 32 &&
                            ((cfg->flags & BN_FLAG_WAVE_KERNEL) || (size_t)p.B * (p.nblk + 1) > kWaveKernelMinWorkgroups);
     if (p.store_u || want_wave) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < kSlots; ++q) {
         alloc(&h->d_cost[q], B * K * 4);
         alloc(&h->d_part[q], B * (size_t)p.nblk * (2 + 2 * T) * 4);
         alloc(&h->d_state_copy[q], B * 3 * 4);
@@ -375,18 +389,31 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     h->lat_kernel = h->pipelined && !h->wave_kernel && !(cfg->flags & BN_FLAG_ROLE_KERNEL) && bn::lat_lds_bytes(p) > 0 &&
                     ((cfg->flags & BN_FLAG_LAT_KERNEL) || (size_t)p.B * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
     if (const char *e = std::getenv("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
-    alloc(&h->d_flags, 8 * sizeof(unsigned long long));
+    alloc(&h->d_flags, ((kSlots + 1) * B + 2) * bn::kFlagStride * sizeof(unsigned long long));
     if (h->lat_kernel && p.nblk <= 16 && 2 * p.T <= bn::kRolloutThreads && !std::getenv("BN_NO_GRANULES"))
-        for (int q = 0; q < 3; ++q) alloc(&h->d_gran[q], B * (size_t)p.nblk * (2 + 2 * T) * sizeof(unsigned long long));
-    if (h->lat_kernel && !(cfg->flags & BN_FLAG_NO_OVERLAP)) {
-        if (h->d_X) alloc(&h->d_X2, B * (T + 1) * 3 * (size_t)p.Kp * 4);
-        if (h->d_U) alloc(&h->d_U2, B * T * 2 * (size_t)p.Kp * 4);
+        for (int q = 0; q < kSlots; ++q) alloc(&h->d_gran[q], B * (size_t)p.nblk * (2 + 2 * T) * sizeof(unsigned long long));
+    // the role kernel (launches that do not leave every workgroup a CU of its own) overlaps its launches as well: a workgroup of
+    // the next solve takes the slot a finished one frees and waits there for ITS instance's previous solve only
+    h->role_overlap = h->pipelined && !h->lat_kernel && !(cfg->flags & BN_FLAG_NO_OVERLAP);
+    if (const char *e = std::getenv("BN_ROLE_OVERLAP")) h->role_overlap = h->role_overlap && e[0] != '0';   // experiments
+    const bool may_overlap = (h->lat_kernel || h->role_overlap) && !(cfg->flags & BN_FLAG_NO_OVERLAP);
+    if (may_overlap) {
+        // Two launches in flight.  Measured with three (role kernel, 64 instances): 23.3 instead of 22.6 us per launch; with
+        // four the launches starve each other of slots (waits expire).  The slot / buffer arithmetic below holds for up to kMaxStreams.
+        h->n_streams = 2;
+        if (const char *e = std::getenv("BN_OVERLAP_STREAMS")) h->n_streams = std::min(std::max(std::atoi(e), 2), kMaxStreams);   // experiments
+        for (int q = 0; q + 1 < h->n_streams; ++q) {
+            if (h->d_X) alloc(&h->d_Xalt[q], B * (T + 1) * 3 * (size_t)p.Kp * 4);
+            if (h->d_U) alloc(&h->d_Ualt[q], B * T * 2 * (size_t)p.Kp * 4);
+        }
     }
-    if (rc == BN_OK && h->lat_kernel) {
-        if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
-            rc = fail(BN_ERR_HIP, "stream / event creation for overlapped launches failed");
+    if (rc == BN_OK && may_overlap) {
+        bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) == hipSuccess;
+        for (int q = 0; ok && q + 1 < h->n_streams; ++q)
+            ok = hipStreamCreateWithFlags(&h->xstream[q], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->ev_join[q], hipEventDisableTiming) == hipSuccess;
+        if (!ok) rc = fail(BN_ERR_HIP, "stream / event creation for overlapped launches failed");
     }
     // (late allocations also go through `alloc`: a failure anywhere destroys the handle and everything it owns)
     if (p.slip_on) {
@@ -425,22 +452,33 @@ void bn_mppi_destroy(bn_mppi_t *h)
     if (!h) return;
     DeviceGuard guard(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
+    {
+        std::lock_guard<std::mutex> lock(g_overlap_mu);
+        auto it = g_overlap_owner.find(h->cfg.device_id);
+        if (it != g_overlap_owner.end() && it->second == h) g_overlap_owner.erase(it);
+    }
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost[0], h->d_cost[1], h->d_cost[2],
-                    h->d_part[0], h->d_part[1], h->d_part[2], h->d_state_copy[0], h->d_state_copy[1], h->d_state_copy[2], h->d_cost_out,
+    void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost_out,
                     h->d_w, h->d_ustar /* d_xstar lives in the same block */, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
                     h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket, h->d_gpart, h->d_mean_used};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->d_flags) (void)hipFree(h->d_flags);
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < kSlots; ++q) {
         if (h->d_gran[q]) (void)hipFree(h->d_gran[q]);
-    if (h->d_X2) (void)hipFree(h->d_X2);
-    if (h->d_U2) (void)hipFree(h->d_U2);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+        if (h->d_cost[q]) (void)hipFree(h->d_cost[q]);
+        if (h->d_part[q]) (void)hipFree(h->d_part[q]);
+        if (h->d_state_copy[q]) (void)hipFree(h->d_state_copy[q]);
+    }
+    for (int q = 0; q < kMaxStreams - 1; ++q) {
+        if (h->d_Xalt[q]) (void)hipFree(h->d_Xalt[q]);
+        if (h->d_Ualt[q]) (void)hipFree(h->d_Ualt[q]);
+        if (h->xstream[q]) { (void)hipStreamSynchronize(h->xstream[q]); (void)hipStreamDestroy(h->xstream[q]); }
+        if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
+    }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -530,7 +568,7 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
 
 // shard_rollout: the rollouts of a K-sharded solve only (bn_mppi_shard_rollout_async); the tail follows the exchange.
 static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise,
-                      bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr, bool alt_buffers = false)
+                      bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr, int alt_buffers = 0)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!states) return fail(BN_ERR_INVALID, "states is null");
@@ -607,7 +645,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     h->last_eps = p.eps;
     h->last_mode = mode;
     const int cur = (int)(h->solves & 1), prev = cur ^ 1;                         // ticket-merge outputs: by parity
-    const int cur3 = (int)(h->solves % 3), prev3 = (int)((h->solves + 2) % 3);    // per-solve buffers: three slots
+    const int cur3 = (int)(h->solves % kSlots), prev3 = (int)((h->solves + kSlots - 1) % kSlots);    // per-solve buffers: kSlots slots
     p.solve = h->solves;
     p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state_copy = h->d_state_copy[cur3];
     p.part_prev = h->d_part[prev3]; p.cost_prev = h->d_cost[prev3]; p.state_prev = h->d_state_copy[prev3];
@@ -626,25 +664,25 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         p.wave_kernel = (h->wave_kernel && !h->in_episode) ? 1 : 0;
         p.lat_kernel = (h->lat_kernel && !h->in_episode) ? 1 : 0;      // device-side episodes advance the state in the role kernel's prologue
         hipStream_t st = h->stream;
-        p.flag_tail = h->d_flags + 3;
+        p.flag_tail = h->d_flags + kSlots * B * bn::kFlagStride;
         if (p.have_prev) {                                             // the aux workgroups write the previous solve's tail
-            p.wait_tail = h->tails;                                    // ... after every tail before it
-            h->tails += (unsigned long long)p.B;
+            p.wait_tail = h->tails;                                    // ... after every tail (of the same instance) before it
+            h->tails += 1;
         }
-        if (p.lat_kernel && overlap) {                                 // member of an overlapped batch: publishes, and waits if its predecessor published
+        if ((p.lat_kernel || h->role_overlap) && overlap) {   // member of an overlapped batch: publishes, and waits if its predecessor published
             p.flag_part = h->d_flags;
-            p.err = reinterpret_cast<int *>(h->d_flags + 4);
+            p.err = reinterpret_cast<int *>(h->d_flags + (kSlots + 1) * B * bn::kFlagStride);
             p.cur_slot = cur3; p.prev_slot = prev3;
             p.wait_part = h->pub[prev3];
-            p.gran = h->d_gran[cur3];
-            if (alt_buffers) {                                         // this solve's trajectories / controls go to the second buffers
-                if (h->d_X2) p.X = h->d_X2;
-                if (h->d_U2 && p.U) p.U = h->d_U2;
+            p.gran = p.lat_kernel ? h->d_gran[cur3] : nullptr;
+            if (alt_buffers) {                                         // this solve's trajectories / controls go to one of the extra buffers
+                if (h->d_Xalt[alt_buffers - 1]) p.X = h->d_Xalt[alt_buffers - 1];
+                if (h->d_Ualt[alt_buffers - 1] && p.U) p.U = h->d_Ualt[alt_buffers - 1];
             }
             p.overlap = (h->prev_published && p.have_prev) ? 1 : 0;
-            p.gran_prev = p.overlap ? h->d_gran[prev3] : nullptr;
+            p.gran_prev = (p.overlap && p.lat_kernel) ? h->d_gran[prev3] : nullptr;
             if (p.overlap) { st = on_stream; h->overlap_used = true; }
-            h->pub[cur3] += (unsigned long long)p.B * p.nblk;
+            h->pub[cur3] += (unsigned long long)p.nblk;
             h->prev_published = true;
         } else {
             h->prev_published = false;
@@ -740,7 +778,7 @@ int bn_mppi_shard_partials(bn_mppi_t *h, const float **partials_device, int32_t 
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->shard_pending) return fail(BN_ERR_STATE, "no sharded solve in flight");
-    const int cur = (int)((h->solves - 1) % 3);
+    const int cur = (int)((h->solves - 1) % kSlots);
     if (partials_device) *partials_device = h->d_part[cur];
     if (workgroups) *workgroups = h->p.nblk;
     if (floats_per_workgroup) *floats_per_workgroup = 2 + 2 * h->p.T;
@@ -754,7 +792,7 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
     if (!all_partials_device || total_workgroups < h->p.nblk) return fail(BN_ERR_INVALID, "need the partials of every shard");
     BN_BIND(h);
     bn::SolveParams p = h->p;
-    const int cur = (int)((h->solves - 1) % 3);
+    const int cur = (int)((h->solves - 1) % kSlots);
     p.solve = p.tail_solve = h->solves - 1;
     p.part = const_cast<float *>(all_partials_device);      // merged in shard order: identical on every rank
     p.nblk = total_workgroups;
@@ -777,9 +815,17 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // the workgroups themselves).  At most two launches are in flight (each stream serialises its own); per-solve buffers
     // rotate over three slots so that what a launch overwrites was last read by a launch that has completed on its stream;
     // the tails (aux workgroups) are ordered by a second counter.  Results are bit-identical to the one-stream chain.
-    const bool overlap = h->lat_kernel && h->stream2 && (h->d_X2 || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE && !h->in_episode &&
+    const bool overlap = (h->lat_kernel || h->role_overlap) && h->n_streams > 1 && (h->d_Xalt[0] || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE && !h->in_episode &&
                          noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending;
-    if (!overlap) {
+    bool mine = overlap;
+    if (overlap) {                                      // see g_overlap_owner
+        BN_BIND(h);
+        std::lock_guard<std::mutex> lock(g_overlap_mu);
+        bn_mppi *&owner = g_overlap_owner[h->cfg.device_id];
+        if (owner && owner != h && hipEventQuery(owner->ev_done) != hipSuccess) { (void)hipGetLastError(); mine = false; }
+        else owner = h;
+    }
+    if (!mine) {
         for (int32_t i = 0; i < n; ++i) {
             const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
             if (int rc = bn_mppi_solve_async(h, states, states_where, e, noise)) return rc;
@@ -787,16 +833,20 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         return BN_OK;
     }
     BN_BIND(h);
-    BN_HIP(hipEventRecord(h->ev_fork, h->stream));                  // fork: the second stream starts behind everything enqueued so far
-    BN_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    const int S = h->n_streams;
+    BN_HIP(hipEventRecord(h->ev_fork, h->stream));                  // fork: the extra streams start behind everything enqueued so far
+    for (int q = 0; q + 1 < S; ++q) BN_HIP(hipStreamWaitEvent(h->xstream[q], h->ev_fork, 0));
     int rc = BN_OK;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
-        rc = solve_impl(h, states, states_where, e, noise, false, true, (i & 1) ? h->stream2 : h->stream, ((n - 1 - i) & 1) != 0);
+        rc = solve_impl(h, states, states_where, e, noise, false, true, (i % S) ? h->xstream[i % S - 1] : h->stream, (n - 1 - i) % S);
     }
-    hipError_t e1 = hipEventRecord(h->ev_join, h->stream2);         // join: the handle's stream continues behind both
-    hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join, 0);
-    if (rc == BN_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(BN_ERR_HIP, "joining the overlapped launches failed");
+    for (int q = 0; q + 1 < S; ++q) {                               // join: the handle's stream continues behind all of them
+        hipError_t e1 = hipEventRecord(h->ev_join[q], h->xstream[q]);
+        hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join[q], 0);
+        if (rc == BN_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(BN_ERR_HIP, "joining the overlapped launches failed");
+    }
+    if (hipEventRecord(h->ev_done, h->stream) != hipSuccess && rc == BN_OK) rc = fail(BN_ERR_HIP, "hipEventRecord failed");
     return rc;
 }
 
@@ -1011,10 +1061,10 @@ int bn_mppi_sync(bn_mppi_t *h)
     BN_HIP(hipStreamSynchronize(h->stream));
     if (h->overlap_used) {                             // a bounded device-side wait of an overlapped launch may have expired
         int err = 0;
-        BN_HIP(hipMemcpy(&err, h->d_flags + 4, sizeof err, hipMemcpyDeviceToHost));
+        BN_HIP(hipMemcpy(&err, h->d_flags + (kSlots + 1) * (size_t)h->p.B * bn::kFlagStride, sizeof err, hipMemcpyDeviceToHost));
         h->overlap_used = false;
         if (err) {
-            BN_HIP(hipMemset(h->d_flags + 4, 0, sizeof(unsigned long long)));
+            BN_HIP(hipMemset(h->d_flags + (kSlots + 1) * (size_t)h->p.B * bn::kFlagStride, 0, sizeof(unsigned long long)));
             return fail(BN_ERR_HIP, "an overlapped launch gave up waiting for its predecessor's partials: results are invalid");
         }
     }
@@ -1050,7 +1100,7 @@ static int reroll_rows(bn_mppi_t *h, int32_t instance, const int *idx_device, in
     if (h->shard_pending) return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
     if (int rc = flush_tail(h)) return rc;
     bn::SolveParams p = h->p;
-    const int cur = (int)((h->solves - 1) % 3);
+    const int cur = (int)((h->solves - 1) % kSlots);
     p.solve = h->solves - 1;
     p.state = h->d_state_copy[cur];
     p.eps = h->last_eps;
@@ -1272,6 +1322,7 @@ int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise)
 int bn_mppi_debug_blocks_per_cu(bn_mppi_t *h) { return bn::rollout_blocks_per_cu(h->p); }
 /* tools/ablate.py only: device buffer of >= 16 uint64 for the in-kernel cycle stamps */
 void bn_mppi_debug_set_stamps(bn_mppi_t *h, void *device_ptr) { h->p.stamps = (unsigned long long *)device_ptr; }
+void bn_mppi_debug_trace_by_parity(bn_mppi_t *h, int on) { h->p.trace_by_parity = on; }
 #endif
 
 int bn_device_math_eval(int32_t fn, const float *in_device, float *out_device, int64_t n, void *stream)

@@ -21,16 +21,29 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 #ifndef BN_ABLATE
 #define BN_ABLATE 0
 #endif
+// Critical-path probes of the overlapped latency kernel (tools/variant_rate.py; results are WRONG with any bit set):
+// 1 column sums without the arithmetic, 2 softmin statistics without max / exp / sum, 4 merge without the arithmetic.
+#ifndef BN_VAR_SKIP
+#define BN_VAR_SKIP 0
+#endif
 #define BN_KEEP(v) asm volatile("" ::"v"(v))
 #ifdef BN_TIMING
 #define BN_STAMP(slot)                                                                                   \
     do {                                                                                                 \
-        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)   /* instance 0, workgroup 0 */ \
+        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { /* instance 0, workgroup 0 */ \
             p.stamps[slot] = __builtin_readcyclecounter();                                               \
+            if ((slot) < 16) p.stamps[32 + ((p.solve & 1) << 4) + (slot)] = wall_clock64();   /* chip-wide 100 MHz clock, by solve parity (tools/stamps_overlap.py) */ \
+        }                                                                                                \
     } while (0)
 #define BN_STAMP_ANY(slot)                                                                               \
     do {                                                                                                 \
         if (p.stamps && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_readcyclecounter(); \
+    } while (0)
+// per-wave cycle stamps of workgroup 0 (tools/stamps_overlap.py): slot i of wave w at stamps[192 + 12 w + i]
+#define BN_WSTAMP(i)                                                                                     \
+    do {                                                                                                 \
+        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)                   \
+            p.stamps[192 + 12 * (threadIdx.x >> 6) + (i)] = __builtin_readcyclecounter();                \
     } while (0)
 // per-workgroup trace (tools/block_trace.py): wall clock (100 MHz, chip-wide) at entry and exit, cycles, HW_ID
 #define BN_TRACE_BEGIN()                                                                                 \
@@ -38,7 +51,7 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 #define BN_TRACE_END()                                                                                   \
     do {                                                                                                 \
         if (p.stamps && threadIdx.x == 0) {                                                              \
-            unsigned long long *r = p.stamps + 64 + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);   \
+            unsigned long long *r = p.stamps + 64 + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x + (p.trace_by_parity ? (size_t)(p.solve & 1) * gridDim.x * gridDim.y : 0));   \
             r[0] = bn_tr_t0; r[1] = wall_clock64(); r[2] = __builtin_readcyclecounter() - bn_tr_c0;      \
             r[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
         }                                                                                                \
@@ -46,6 +59,7 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 #else
 #define BN_STAMP(slot) do { } while (0)
 #define BN_STAMP_ANY(slot) do { } while (0)
+#define BN_WSTAMP(i) do { } while (0)
 #define BN_TRACE_BEGIN() do { } while (0)
 #define BN_TRACE_END() do { } while (0)
 #endif
@@ -326,11 +340,18 @@ __device__ __forceinline__ void st(float *ptr, float v) { if (AGENT) store_agent
 // Overlapped launches: a counter another launch advances (device-scope atomics) reaches `need`.  ONE lane polls, with sc1 loads
 // and s_sleep in between; the caller puts a workgroup barrier behind it.  Bounded: a wait that does not end within ~2 s sets
 // *err and gives up -- a wrong result that bn_mppi_sync reports, never a hung GPU.
+// SLEEP: s_sleep argument between polls (x 64 cycles).  1 where the wait is short and on the critical path (latency kernel); the
+// role kernel's workgroups may hold a slot for many microseconds with hundreds of them polling at once -- at s_sleep 1 their
+// loads saturate the memory channel the counters live in and everything else that touches it (measured: 40 instances, 31 us
+// per launch instead of 21) -- so they poll every ~0.5 us, and the counters are kFlagStride apart (one channel each).
+__device__ __forceinline__ unsigned long long *flag_ctr(unsigned long long *base, int i) { return base + (size_t)i * kFlagStride; }
+
+template <int SLEEP = 1>
 __device__ __forceinline__ void wait_counter(const unsigned long long *ctr, unsigned long long need, int *err)
 {
-    for (int it = 0; it < (1 << 23); ++it) {
+    for (int it = 0; it < (1 << 23) / SLEEP + 1024; ++it) {
         if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SLEEP);
     }
     __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -371,8 +392,10 @@ __device__ __forceinline__ void column_sums(const float *Ul, const float *el, in
         const int j = it >> 2, r = it & 3;
         const float *col = Ul + j * kUPad + 16 * r, *e = el + 16 * r;
         float acc = 0.0f;
+        if (BN_VAR_SKIP & 1) acc = e[0] * col[0]; else
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc = __builtin_fmaf(e[q], col[q], acc);
+        if (!(BN_VAR_SKIP & 1))
         asm volatile("s_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
@@ -514,6 +537,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 #define BN_SCALE(i) __int_as_float(__builtin_amdgcn_readlane(fb, (i)))
         for (int jj = tid; jj < 2 * T; jj += NT) {
             float acc = 0.0f;
+            if (BN_VAR_SKIP & 4) { us[jj] = L.v[0] * 1e-3f; continue; }
             if (jj == L.j) {
 #pragma unroll
                 for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], BN_SCALE(i), acc);   // f == 0 past nblk
@@ -571,8 +595,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
 {
     if (AGENT) {
         if (threadIdx.x == 0) {
-            wait_counter(p.flag_part + p.prev_slot, p.wait_part, p.err);      // the solve whose tail this is has published everything
-            wait_counter(p.flag_tail, p.wait_tail, p.err);                   // and the tail before it has left the output buffers
+            wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p.err);   // the solve whose tail this is has published everything
+            wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p.err);               // and the tail before it has left the output buffers
         }
         __syncthreads();
     }
@@ -770,7 +794,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         }
     }
     // one more tail done (counted per instance): what an overlapped successor's tail waits for before it takes the output buffers
-    if (p.flag_tail) publish_counter(p.flag_tail, tid);
+    if (p.flag_tail) publish_counter(flag_ctr(p.flag_tail, b), tid);
 }
 
 // Ticket merge: every workgroup of instance b publishes its partials, takes a ticket, and the one that draws the

@@ -89,10 +89,10 @@ struct SolveParams {
     // may start while its predecessor still runs; what stream order used to guarantee is carried by monotonic device counters ----
     int overlap;                         // this launch must WAIT on the counters (its predecessor is on the other stream)
     int cur_slot, prev_slot;             // slots (0..2) of this solve's and the previous solve's per-solve buffers
-    unsigned long long *flag_part;       // [3] rollout workgroups that have published their partials into slot j, ever
-    unsigned long long *flag_tail;       // tails (aux workgroups / finish kernels, one count per instance) completed, ever
-    unsigned long long wait_part;        // flag_part[prev_slot] value that means "the previous solve's partials and costs are all there"
-    unsigned long long wait_tail;        // flag_tail value that means "the tail before the one this launch carries is done"
+    unsigned long long *flag_part;       // [3][B] rollout workgroups of instance b that have published their partials into slot j, ever
+    unsigned long long *flag_tail;       // [B] tails (aux workgroups / finish kernels) of instance b completed, ever
+    unsigned long long wait_part;        // flag_part[prev_slot][b] value that means "the previous solve's partials and costs of this instance are all there"
+    unsigned long long wait_tail;        // flag_tail[b] value that means "the tail before the one this launch carries is done"
     int *err;                            // set non-zero when a bounded wait expired (reported by bn_mppi_sync)
     unsigned long long *gran, *gran_prev;   // (B, nblk, 2+2T) granule copies {value, tag} of this / the previous solve's partial rows
                                             // (overlapped batches with K <= 1024: the successor's prologue polls the rows themselves)
@@ -102,8 +102,11 @@ struct SolveParams {
     float *out_copy;     // optional caller-owned copy of the packed (B,T,2) U* | (B,T+1,3) X* block, written by the same tail
                          // (bn_mppi_forward_async: the drop-in class's fresh output tensors without a second launch)
     float *stats;        // (B, 2): max z, sum exp
+    int trace_by_parity;          // timing builds: per-workgroup trace rows of odd solves behind those of even solves (two launches in flight)
     unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0
 };
+
+constexpr int kFlagStride = 32;            // spacing of the overlap counters, in counters of 8 bytes: 256 bytes, one memory channel each
 
 // Launch grid of the rollout kernels.  x = workgroup-of-instance index interleaved with 2^xs instances, y = groups of
 // 2^xs instances, then -- LAST in dispatch order -- the rows holding the B aux workgroups (tail of the previous solve):

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     if (wg.idle) return;
     if (wg.aux) {
         if (p.aux_prio) __builtin_amdgcn_s_setprio(3);
-        finish_body<GEO, LDSWIN, 64>(p, wg.b, p.part_prev, p.cost_prev, p.state_prev, smem);
+        if (p.overlap) finish_body<GEO, LDSWIN, 64, false, true>(p, wg.b, p.part_prev, p.cost_prev, p.state_prev, smem);
+        else finish_body<GEO, LDSWIN, 64>(p, wg.b, p.part_prev, p.cost_prev, p.state_prev, smem);
         return;
     }
     const int T = p.T, K = p.K;
@@ -44,15 +45,23 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
 
     const float *part_prev = p.part_prev + (size_t)b * p.nblk * (2 + 2 * T);
+    // overlapped launch: the previous solve of this instance may still run in a launch on the other stream (rollout_role.inc)
+    const bool ov = p.overlap && p.mean_from_part;
     MergeLoads pre{};
-    const bool pre_ok = p.mean_from_part && p.nblk <= 64;
+    const bool pre_ok = p.mean_from_part && p.nblk <= 64 && !ov;
     if (pre_ok) pre = merge_issue(part_prev, p.nblk, T, lane);
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN) {
         w = window_origin<GEO>(p, sx, sy);
         stage_window(win, map, w, p.WN, p.G, lane, 64);
     }
-    if (p.mean_from_part) {
+    if (ov) {
+        if (lane == 0) wait_counter<16>(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p.err);
+        __syncthreads();
+        float m_unused, S_unused;
+        merge_partials<64, true>(part_prev, p.nblk, T, ml, sc, sc + p.nblk, lane, m_unused, S_unused, false, pre);
+        for (int j = lane; j < 2 * T; j += 64) mv[j] = ml[j] * ((j & 1) ? p.iv1 : p.iv0);
+    } else if (p.mean_from_part) {
         float m_unused, S_unused;
         merge_partials<64>(part_prev, p.nblk, T, ml, sc, sc + p.nblk, lane, m_unused, S_unused, pre_ok, pre);
         for (int j = lane; j < 2 * T; j += 64) mv[j] = ml[j] * ((j & 1) ? p.iv1 : p.iv0);
@@ -63,8 +72,10 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
             mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);      // mean[t] @ inv_cov (diagonal), mppi.py:179-180
         }
     }
+    const bool pub = p.flag_part != nullptr;           // member of an overlapped batch: what a successor reads goes out as device-scope stores
     if (wg.blk == 0 && lane == 0) {
-        p.state_copy[b * 3 + 0] = sx; p.state_copy[b * 3 + 1] = sy; p.state_copy[b * 3 + 2] = sth;
+        if (pub) { store_agent(p.state_copy + b * 3 + 0, sx); store_agent(p.state_copy + b * 3 + 1, sy); store_agent(p.state_copy + b * 3 + 2, sth); }
+        else { p.state_copy[b * 3 + 0] = sx; p.state_copy[b * 3 + 1] = sy; p.state_copy[b * 3 + 2] = sth; }
     }
     __syncthreads();
     const size_t Kp = (size_t)p.Kp;
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     const float dxT = c.x - gx, dyT = c.y - gy;
     const float term = sqrt_cr(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);      // mppi.py:184
     const float cost = ((float)Sd + term) + (float)Ad;                                          // mppi.py:186-190
-    if (active) p.cost[(size_t)b * K + k] = cost;
+    if (active) { if (pub) store_agent(p.cost + (size_t)b * K + k, cost); else p.cost[(size_t)b * K + k] = cost; }
     const float z = active ? (-cost) / p.lambda_ : -INFINITY;
     const float zmax = wave_max(z);
     const float e = active ? expf(z - zmax) : 0.0f;
@@ -122,7 +133,10 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     el[lane] = e;
     __syncthreads();                                   // e in LDS; this wave's control stores visible to all its lanes
     float *part = p.part + ((size_t)b * p.nblk + wg.blk) * (2 + 2 * T);
-    if (lane == 0) { part[0] = zmax; part[1] = esum; }
+    if (lane == 0) {
+        if (pub) { store_agent(part, zmax); store_agent(part + 1, esum); }
+        else { part[0] = zmax; part[1] = esum; }
+    }
     // weighted control sums: lane = column j, whose 64 rollout values are one contiguous row of the (T,2,Kp) buffer
     const float *Urow0 = p.U + (size_t)b * T * 2 * Kp + (size_t)wg.blk * kRolloutsPerBlock;
     for (int j = lane; j < 2 * T; j += 64) {
@@ -145,8 +159,9 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
             if (r & 1) { pair = pair + a_; acc = (r == 1) ? pair : acc + pair; }
             else pair = a_;
         }
-        part[2 + j] = acc;
+        if (pub) store_agent(part + 2 + j, acc); else part[2 + j] = acc;
     }
+    if (pub) publish_counter(flag_ctr(p.flag_part, p.cur_slot * p.B + b), lane);
 }
 
 

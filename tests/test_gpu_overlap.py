@@ -59,6 +59,77 @@ def test_overlapped_chain_equals_one_stream_chain(K, T, B, noise, lean, n):
             assert np.array_equal(a_, b_), (b, j)
 
 
+@pytest.mark.parametrize("kernel,K,T,B,noise,lean,n", [("role", 1024, 50, 2, "philox", False, 9), ("role", 1000, 33, 3, "kt2", False, 6),
+                                                        ("role", 512, 20, 40, "philox", False, 8), ("role", 1024, 50, 70, "philox", True, 7),
+                                                        ("role", 256, 12, 300, "philox", False, 5),
+                                                        ("wave", 1024, 50, 3, "philox", False, 8), ("wave", 1000, 33, 2, "t2k", False, 6),
+                                                        ("wave", 512, 20, 150, "philox", False, 6), ("wave", 512, 20, 150, "philox", True, 5)],
+                         ids=["role-B2", "role-ragged-kt2", "role-B40", "role-B70-lean", "role-B300-two-rounds", "wave-B3", "wave-ragged-t2k", "wave-B150",
+                              "wave-B150-lean"])
+def test_many_instance_kernels_overlap_their_launches_bit_identically(kernel, K, T, B, noise, lean, n):
+    """The role kernel and the one-wave throughput kernel publish per instance and wait per instance: a workgroup of solve i+1
+    takes the slot a finished workgroup of solve i leaves and waits there for its own instance only.  Same bar as above."""
+    import torch
+    from benchnav_amd import _capi, synth
+    base = [synth.make_instance(G, seed=90 + b, jitter=True) for b in range(min(B, 6))]
+    insts = [base[b % len(base)] for b in range(B)]
+    st = torch.stack([it.start for it in insts]).clone()
+    st[:, 0] += torch.arange(B) * 0.01                      # instances differ even where they share a map
+    st = st.cuda()
+    ring = min(n, 3)
+    ed, kind, stride = None, _capi.BN_NOISE_PHILOX, 0
+    if noise != "philox":
+        eps = np.random.default_rng(8).standard_normal((ring, B, K, T, 2)).astype(np.float32)
+        stride = eps[0].size
+        if noise == "kt2":
+            ed, kind = torch.from_numpy(eps).cuda(), _capi.BN_NOISE_DEVICE_KT2
+        else:
+            ed, kind = torch.from_numpy(np.ascontiguousarray(eps.transpose(0, 1, 3, 4, 2))).cuda(), _capi.BN_NOISE_DEVICE_T2K
+    torch.cuda.synchronize()
+    res = {}
+    for overlap in (False, True):
+        with _make(K, T, B, insts, overlap, store_controls=not lean, lean=lean, kernel=kernel) as pl:
+            if ed is None:
+                pl.solve_n_async_device(n, st.data_ptr())
+            else:
+                pl.solve_n_async_device(n, st.data_ptr(), ed.data_ptr(), kind, ring, stride)
+            pick = sorted(set([0, B // 3, B // 2, B - 1]))
+            out = _outputs(pl, B, T)
+            res[overlap] = [out[b] for b in pick]
+    for a, c in zip(res[True], res[False]):
+        for j, (a_, c_) in enumerate(zip(a, c)):
+            assert np.array_equal(a_, c_), j
+
+
+def test_two_handles_in_flight_do_not_starve_each_other():
+    """Workgroups of an overlapped launch hold their slots while they wait.  Several handles doing that at once can leave no
+    slot for each other's predecessors; the library lets one handle per device overlap at a time and runs the other's batch
+    in one stream.  Eight planners enqueue long batches back to back without a sync in between: no wait expires (sync() would
+    raise), and each ends where its own one-stream run ends."""
+    import torch
+    from benchnav_amd import synth
+    K, T, B, n = 1024, 50, 8, 60
+    insts = [synth.make_instance(G, seed=11 + b) for b in range(B)]
+    st = torch.stack([it.start for it in insts]).cuda()
+    torch.cuda.synchronize()
+    with _make(K, T, B, insts, False) as ref:
+        ref.solve_n_async_device(n, st.data_ptr())
+        want = _outputs(ref, B, T)
+    planners = [_make(K, T, B, insts, True) for _ in range(8)]
+    try:
+        for rep in range(2):
+            for pl in planners:
+                pl.solve_n_async_device(n // 2, st.data_ptr())
+        for pl in planners:
+            got = _outputs(pl, B, T)                     # sync() inside raises if a device-side wait gave up
+            for b in (0, B - 1):
+                for j, (a_, c_) in enumerate(zip(got[b], want[b])):
+                    assert np.array_equal(a_, c_), (b, j)
+    finally:
+        for pl in planners:
+            pl.close()
+
+
 def test_fresh_handles_keep_the_last_solves_trajectories():
     """Two launches in flight never write the same trajectory / control addresses (the batch alternates between two buffers and
     ends on the exposed one).  A cold handle is where a late-ending earlier kernel used to overwrite rows of the last solve:

@@ -41,6 +41,14 @@ for B in [int(x) for x in os.environ.get("BN_BS", "16,32,60,64,128").split(",")]
           f" | end med {q(t1[rol],50):.1f} p90 {q(t1[rol],90):.1f} max {t1[rol].max():.1f}\n"
           f"   aux    : start min {t0[aux].min():.1f} med {q(t0[aux],50):.1f} max {t0[aux].max():.1f} | dur med {q(dur[aux],50):.1f} max {dur[aux].max():.1f} | end med {q(t1[aux],50):.1f} max {t1[aux].max():.1f}\n"
           f"   rollout workgroups per CU: min {cnt.min()} median {int(np.median(cnt))} max {cnt.max()} on {len(uniq)} CUs | per XCC {np.bincount(xcc[rol], minlength=8).tolist()}")
+    # CUs per shader engine (harvesting can leave them unequal) against the workgroups each engine was dealt
+    se_key = xcc * 10 + se
+    per_se = []
+    for k in np.unique(se_key[rol]):
+        m = rol & (se_key == k)
+        per_se.append((len(np.unique(place[m])), int(m.sum()), int((m & (t0 > 5.0)).sum())))
+    from collections import Counter
+    print("   shader engines by (CUs, rollout workgroups dealt, of those started late):", dict(Counter(per_se)))
     tg = (hw >> 16) & 0xf
     # duration by start rank within the CU (0 = first workgroup the CU received), and whether the slot ids are distinct
     by_rank = {k: [] for k in range(8)}
