@@ -100,16 +100,23 @@ __device__ __forceinline__ int raw_cell(float v, float origin, float res, float 
     return (int)floorf(q);                    // v_cvt_i32_f32 saturates
 }
 
+// Window of edge wn covering `reach` cells either side of the cell of (sx, sy), shifted into the map.
 template <int GEO>
-__device__ __forceinline__ Win window_origin(const SolveParams &p, float sx, float sy)
+__device__ __forceinline__ Win window_origin_wide(const SolveParams &p, float sx, float sy, int reach, int wn)
 {
     const int cx = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
     const int cy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
     Win w;
-    w.wx0 = min(max(cx - p.reach, 0), p.G - p.WN);
-    w.wy0 = min(max(cy - p.reach, 0), p.G - p.WN);
-    w.fx0 = (float)w.wx0; w.fy0 = (float)w.wy0; w.fwn = (float)p.WN; w.fwm1 = (float)(p.WN - 1);
+    w.wx0 = min(max(cx - reach, 0), p.G - wn);
+    w.wy0 = min(max(cy - reach, 0), p.G - wn);
+    w.fx0 = (float)w.wx0; w.fy0 = (float)w.wy0; w.fwn = (float)wn; w.fwm1 = (float)(wn - 1);
     return w;
+}
+
+template <int GEO>
+__device__ __forceinline__ Win window_origin(const SolveParams &p, float sx, float sy)
+{
+    return window_origin_wide<GEO>(p, sx, sy, p.reach, p.WN);
 }
 
 // Stage the reachable window as traversability: trav = 1 - clamp(risk, 0, 1)
@@ -209,17 +216,27 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
 // Every workgroup that needs the next state evaluates this itself: same inputs, same operations.
 struct EnvStep { float x, y, th, reward; bool reached, frozen; };
 
+// The latent slip model at the cell of (sx, sy): the two loads of env_advance, issued on their own so that a caller who knows the
+// state early can have them in flight while it waits for the control.
+struct EnvCell { float mean, std; };
+
 template <int GEO>
-__device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, float sx, float sy, float sth, float u0, float u1,
-                                               const float *z_ptr, uint64_t step)
+__device__ __forceinline__ EnvCell env_fetch(const SolveParams &p, int b, float sx, float sy)
+{
+    const int ix = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
+    const int iy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
+    const size_t cell = (size_t)b * p.map_stride + (size_t)iy * p.G + ix;
+    return EnvCell{p.lat_mean[cell], p.lat_std[cell]};
+}
+
+template <int GEO>
+__device__ __forceinline__ EnvStep env_advance_with(const SolveParams &p, int b, float sx, float sy, float sth, float u0, float u1,
+                                                    const float *z_ptr, uint64_t step, const EnvCell lc)
 {
     const float gx = p.goal[b * 2 + 0], gy = p.goal[b * 2 + 1];
     EnvStep r;
     const float d0x = sx - gx, d0y = sy - gy;
     r.frozen = p.env_freeze && sqrt_cr(d0x * d0x + d0y * d0y) < p.goal_thr;      // terminated at an earlier step
-    const int ix = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
-    const int iy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
-    const size_t cell = (size_t)b * p.map_stride + (size_t)iy * p.G + ix;
     float z;
     if (z_ptr) {
         z = z_ptr[b];
@@ -229,7 +246,7 @@ __device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, floa
         float z1;
         box_muller(q.x, q.y, z, z1);
     }
-    const float slip = z * p.lat_std[cell] + p.lat_mean[cell];
+    const float slip = z * lc.std + lc.mean;
     const float trav = 1.0f - clampf(slip, 0.0f, 1.0f);
     const float v = clampf(u0, p.umin0, p.umax0), om = clampf(u1, p.umin1, p.umax1);   // robot_model.py:82-83
     float sn, cs;
@@ -244,6 +261,13 @@ __device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, floa
     const float dx = r.x - gx, dy = r.y - gy;
     r.reached = sqrt_cr(dx * dx + dy * dy) < p.goal_thr;             // planetary_env.py:215-217
     return r;
+}
+
+template <int GEO>
+__device__ __forceinline__ EnvStep env_advance(const SolveParams &p, int b, float sx, float sy, float sth, float u0, float u1,
+                                               const float *z_ptr, uint64_t step)
+{
+    return env_advance_with<GEO>(p, b, sx, sy, sth, u0, u1, z_ptr, step, env_fetch<GEO>(p, b, sx, sy));
 }
 
 // Sampled-slip helpers (BASELINE config 3, see rollout_sampled_kernel): every lookup evaluates the observation-mode
@@ -664,7 +688,11 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             float *row0 = p.ep_states + (size_t)b * 3;
             row0[0] = sx; row0[1] = sy; row0[2] = sth;
         }
-        if (e.reached && !e.frozen && p.ep_done[b] < 0) p.ep_done[b] = p.ep_index;
+        // (tails of consecutive solves may run in different launches in flight at once: device-scope accesses, like the mean)
+        if (e.reached && !e.frozen) {
+            const int seen = AGENT ? __hip_atomic_load(p.ep_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.ep_done[b];
+            if (seen < 0) { if (AGENT) __hip_atomic_store(p.ep_done + b, p.ep_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else p.ep_done[b] = p.ep_index; }
+        }
     }
     BN_STAMP(10);
 

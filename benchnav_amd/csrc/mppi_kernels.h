@@ -22,6 +22,8 @@ struct SolveParams {
     int Kp;              // row pitch of X and U in floats: 64 * nblk (lanes past K store into the pad)
     int WN;              // LDS window edge in cells, 0 = gather from global memory
     int reach;           // ceil(T * vmax * dt / res) + 1 cells
+    int spec_extra;      // device-side episodes, latency kernel: cells the state can move in ONE environment step, + 1.  The window is
+                         // staged this much wider around the PREVIOUS state while the new one is not known yet; 0 = stage afterwards
     int map_stride;      // G*G if every instance has its own map, 0 if shared
     int pow2;            // resolution is a power of two
     int store_u;

@@ -101,6 +101,37 @@ def test_many_instance_kernels_overlap_their_launches_bit_identically(kernel, K,
             assert np.array_equal(a_, c_), j
 
 
+@pytest.mark.parametrize("K,T,B,n,corner", [(1024, 50, 1, 40, False), (512, 20, 3, 60, True), (256, 12, 40, 30, False), (1024, 50, 20, 12, False)],
+                         ids=["c2", "B3-map-corner", "B40", "role-B20"])
+def test_overlapped_episodes_log_the_same_closed_loop(K, T, B, n, corner):
+    """Device-side episodes with overlapped launches: the successor reads the state its predecessor advanced (counter path:
+    device-scope loads after the wait; latency kernel: three tagged granules, polled EARLY so that the latent-slip loads and a
+    window one environment step wider are in flight before the control is known).  Same log, same final solve as one stream,
+    for the latency kernel, the role kernel, and starts in a map corner (the wider window is shifted into the map)."""
+    import torch
+    from benchnav_amd import synth
+    base = [synth.make_instance(G, seed=40 + b, jitter=True) for b in range(min(B, 4))]
+    insts = [base[b % len(base)] for b in range(B)]
+    starts = np.stack([it.start.numpy() for it in insts]).astype(np.float32)
+    starts[:, 0] += np.arange(B, dtype=np.float32) * 0.02
+    if corner:
+        starts[0, :2] = [0.2, 0.3]; starts[-1, :2] = [G * 0.5 - 0.3, G * 0.5 - 0.2]
+    lat = np.stack([it.risk.numpy() for it in insts]); std = np.full_like(lat, 0.08)
+    res = {}
+    for overlap in (False, True):
+        with _make(K, T, B, insts, overlap) as pl:
+            pl.env_attach(lat, std, goal_threshold=1.0, delta_t=0.1, seed=77)
+            log = pl.episode(n, starts)
+            res[overlap] = (log, pl.last_actions.copy(), _outputs(pl, B, T))
+    (s0, r0, d0), a0, o0 = res[False]
+    (s1, r1, d1), a1, o1 = res[True]
+    assert np.array_equal(s0, s1) and np.array_equal(r0, r1) and np.array_equal(d0, d1) and np.array_equal(a0, a1)
+    assert np.abs(np.diff(s0[:, :, :2], axis=0)).max() > 1e-3                     # the rovers do move
+    for b in (0, B - 1):
+        for j, (x, y) in enumerate(zip(o1[b], o0[b])):
+            assert np.array_equal(x, y), (b, j)
+
+
 def test_two_handles_in_flight_do_not_starve_each_other():
     """Workgroups of an overlapped launch hold their slots while they wait.  Several handles doing that at once can leave no
     slot for each other's predecessors; the library lets one handle per device overlap at a time and runs the other's batch

@@ -15,11 +15,12 @@ for B in [int(x) for x in os.environ.get("BN_BS", "16,32,64,128").split(",")]:
             for b, it in enumerate(insts):
                 pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
             pl.solve_n_async_device(50, st.data_ptr()); pl.sync()
-            best = 1e9
-            for _ in range(3):
+            best, worst = 1e9, 0.0
+            for _ in range(int(os.environ.get("BN_REPS", "3"))):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 pl.solve_n_async_device(400, st.data_ptr()); pl.sync()
-                best = min(best, (time.perf_counter() - t0) / 400)
+                dt_ = (time.perf_counter() - t0) / 400
+                best, worst = min(best, dt_), max(worst, dt_)
             by = pl.algorithmic_bytes(injected_noise=False) * B
-            print(f"B={B:4d} lean={lean!s:5s} overlap={overlap!s:5s}: {best * 1e6:7.2f} us per launch  {B / best / 1e6:5.2f} M solves/s  {by / best / 1e12:5.2f} TB/s", flush=True)
+            print(f"B={B:4d} lean={lean!s:5s} overlap={overlap!s:5s}: {best * 1e6:7.2f} us per launch  {B / best / 1e6:5.2f} M solves/s  {by / best / 1e12:5.2f} TB/s   (slowest batch {worst * 1e6:7.2f} us)", flush=True)
             pl.close()

@@ -11,7 +11,7 @@ from benchnav_amd import NativeMPPI, synth
 inst = synth.make_instance(256, seed=0)
 NBLK = 16
 for B in [int(x) for x in os.environ.get("BN_BS", "40,64").split(",")]:
-    pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, num_instances=B, shared_map=True, kernel="role")
+    pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, num_instances=B, shared_map=True, kernel=os.environ.get("BN_KERNEL", "role"))
     pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
     nb = NBLK * (B + (B + NBLK - 1) // NBLK)
     stamps = torch.zeros(64 + 4 * 2 * nb, dtype=torch.int64, device="cuda")
@@ -21,7 +21,12 @@ for B in [int(x) for x in os.environ.get("BN_BS", "40,64").split(",")]:
     pl._lib.bn_mppi_debug_trace_by_parity(pl._h, 1)
     st = torch.stack([inst.start] * B).cuda(); torch.cuda.synchronize()
     n = 41
-    pl.solve_n_async_device(n, st.data_ptr()); pl.sync()
+    if os.environ.get("BN_EPISODE"):
+        lat = inst.risk.numpy()[None]; pl.env_attach(lat, np.full_like(lat, 0.05))
+        pl.episode(n, np.stack([inst.start.numpy()] * B))
+        pl.episode(n, np.stack([inst.start.numpy()] * B))
+    else:
+        pl.solve_n_async_device(n, st.data_ptr()); pl.sync()
     total = pl.solve_count()
     r = stamps.cpu().numpy()[64:].reshape(2, nb, 4).astype(np.int64)
     last, prev = r[(total - 1) & 1], r[(total - 2) & 1]          # the final launch and the one before it

@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from benchnav_amd import NativeMPPI, synth
 G, K, T = 256, 1024, 50
-for B in (1, 8, 64):
+cases = [(int(x), bool(int(y))) for x, y in (c.split(":") for c in os.environ.get("BN_CASES", "1:1,1:0,8:1,8:0,64:1,64:0").split(","))]
+for B, overlap in cases:
     insts = [synth.make_instance(G, seed=s, jitter=True) for s in range(min(B, 8))]
-    pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, stream=0)
+    pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, stream=(None if os.environ.get('BN_STREAM') == 'private' else 0), overlap=overlap, kernel=os.environ.get('BN_KERNEL', 'auto'))
     for b in range(B):
         it = insts[b % len(insts)]; pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
     lat = np.stack([insts[b % len(insts)].risk.numpy() for b in range(B)]); std = np.full_like(lat, 0.05)
@@ -14,8 +15,10 @@ for B in (1, 8, 64):
     starts = np.stack([insts[b % len(insts)].start.numpy() for b in range(B)])
     pl.episode(200, starts)
     n = 2000
-    t = time.perf_counter(); states, rewards, done = pl.episode(n, starts); dt = time.perf_counter() - t
+    dt = 1e9
+    for _ in range(3):      # best of three: the first long burst of launches of a process can stall ~0.1 s in the runtime (host side, once)
+        t = time.perf_counter(); states, rewards, done = pl.episode(n, starts); dt = min(dt, time.perf_counter() - t)
     dist0 = np.linalg.norm(states[0, :, :2] - np.stack([insts[b % len(insts)].goal.numpy() for b in range(B)]), axis=1)
     dist1 = np.linalg.norm(states[-1, :, :2] - np.stack([insts[b % len(insts)].goal.numpy() for b in range(B)]), axis=1)
-    print(f"B={B}: {n} closed-loop steps in {dt*1e3:.1f} ms -> {dt/n*1e6:.1f} us/step, {B*n/dt:.0f} control steps/s; reached {int((done>=0).sum())}/{B}; mean distance to goal {dist0.mean():.1f} -> {dist1.mean():.1f} m; mean reward {rewards.mean():.2f}")
+    print(f"B={B} overlap={overlap}: {n} closed-loop steps in {dt*1e3:.1f} ms -> {dt/n*1e6:.1f} us/step, {B*n/dt:.0f} control steps/s; reached {int((done>=0).sum())}/{B}; mean distance to goal {dist0.mean():.1f} -> {dist1.mean():.1f} m; mean reward {rewards.mean():.2f}")
     pl.close()
