@@ -292,8 +292,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                         "kernel": "bn::rollout_kernel (5 role-specialised waves per 64 rollouts; in the pipelined "
-                                   "mode it also carries the previous solve's merge + tail workgroup)",
+                         "kernel": "bn::rollout_lat_kernel (barrier-free variant of the 5-wave role kernel, one workgroup per CU; "
+                                   "every launch also carries the previous solve's merge + tail workgroup)",
                          "kernel_ms": kernel_ms,
                          "kernel_ms_source": "HIP event pair on the launch stream around the same K launches on the same handle, right after "
                                              "the timed repeats (median; launch-to-launch mean).  With overlapped launches (default) two kernels "
