@@ -54,10 +54,11 @@ bool is_pow2_float(float v)
 // One overlapped batch per device at a time.  Workgroups of an overlapped launch hold their slots while they wait for their
 // predecessor; two handles doing that at once can starve each other's predecessors of slots until the bounded waits expire
 // (8 handles x 8 instances: seen).  A handle overlaps only while no OTHER handle's overlapped batch is still in flight on its
-// device (`ev_done` of the owner not yet reached); otherwise this batch runs in one stream, which is always safe.
+// device (its streams still busy); otherwise this batch runs in one stream, which is always safe.
 std::mutex g_overlap_mu;
 std::map<int, bn_mppi *> g_overlap_owner;   // device -> the handle whose overlapped batch was enqueued last
 
+constexpr int kEagerTailMinBatch = 16;    // overlapped batches of at least this many solves end with their own tail kernel
 constexpr int kMaxStreams = 3;            // launches of one overlapped batch in flight at most
 constexpr int kSlots = kMaxStreams + 1;   // per-solve buffer slots (see bn_mppi::d_cost)
 
@@ -93,12 +94,13 @@ struct bn_mppi {
     std::vector<float> dwa_stage;    // host staging of bn_mppi_dwa_solve's upload
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
+    int n_cus = 256;
     size_t resident_wgs = 1024;      // role-kernel workgroups the device holds at once (LDS- and wave-limited) x CUs
     // overlapped launches: consecutive solves of one bn_mppi_solve_n_async call go round the handle's stream and n_streams - 1
     // extra ones; device counters carry the dependency (SolveParams.flag_part / flag_tail)
     int n_streams = 1;
     hipStream_t xstream[kMaxStreams - 1] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams - 1] = {}, ev_done = nullptr;   // ev_done: behind everything of the latest overlapped batch
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams - 1] = {};
     unsigned long long *d_flags = nullptr;      // [kSlots][B] flag_part per slot and instance, [B] flag_tail per instance, then int err
     bool role_overlap = false;                  // the role kernel's launches of a batch may overlap too (see bn_mppi_solve_n_async)
     unsigned long long *d_gran[kSlots] = {};   // granule copies of the partial rows per slot (K <= 1024, 2T <= 320)
@@ -329,6 +331,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         const size_t by_lds = lds_budget / std::max<size_t>(bn::rollout_lds_bytes(p), 1);
         const size_t by_waves = 32 / (bn::kRolloutThreads / 64);
         h->resident_wgs = std::max<size_t>(1, std::min(by_lds, by_waves)) * (size_t)std::max(prop.multiProcessorCount, 1);
+        h->n_cus = std::max(prop.multiProcessorCount, 1);
     }
     int rc = BN_OK;
     auto alloc = [&](auto **ptr, size_t bytes) {
@@ -408,8 +411,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         }
     }
     if (rc == BN_OK && may_overlap) {
-        bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) == hipSuccess;
+        bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
         for (int q = 0; ok && q + 1 < h->n_streams; ++q)
             ok = hipStreamCreateWithFlags(&h->xstream[q], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&h->ev_join[q], hipEventDisableTiming) == hipSuccess;
@@ -457,7 +459,6 @@ void bn_mppi_destroy(bn_mppi_t *h)
         auto it = g_overlap_owner.find(h->cfg.device_id);
         if (it != g_overlap_owner.end() && it->second == h) g_overlap_owner.erase(it);
     }
-    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost_out,
                     h->d_w, h->d_ustar /* d_xstar lives in the same block */, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
@@ -824,8 +825,13 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         BN_BIND(h);
         std::lock_guard<std::mutex> lock(g_overlap_mu);
         bn_mppi *&owner = g_overlap_owner[h->cfg.device_id];
-        if (owner && owner != h && hipEventQuery(owner->ev_done) != hipSuccess) { (void)hipGetLastError(); mine = false; }
-        else owner = h;
+        if (owner && owner != h) {                      // is the owner's latest overlapped batch still in flight?
+            bool busy = hipStreamQuery(owner->stream) != hipSuccess;
+            for (int q = 0; !busy && q + 1 < owner->n_streams; ++q) busy = hipStreamQuery(owner->xstream[q]) != hipSuccess;
+            (void)hipGetLastError();
+            if (busy) mine = false;
+        }
+        if (mine) owner = h;
     }
     if (!mine) {
         for (int32_t i = 0; i < n; ++i) {
@@ -836,19 +842,40 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     }
     BN_BIND(h);
     const int S = h->n_streams;
+    // The scheme relies on a launch having been dispatched before its successor becomes eligible: waiting workgroups hold their
+    // slots, and the hardware does not share freed slots fairly between two queues (seen with two 70-instance launches made
+    // eligible at the same instant: the successor's waiting workgroups took every slot, the predecessor's never got one, the
+    // waits expired).  Inside a batch that holds by construction -- launch i+1 becomes eligible when launch i-1 completes, a whole
+    // kernel after launch i did.  At the START it holds when the stream is idle (solve 1 is enqueued microseconds after solve 0
+    // went out); if earlier work is still pending, solves 0 and 1 would become eligible together, so launches big enough to
+    // crowd each other out wait for the stream first.
+    const size_t slots = h->wave_kernel ? 24 * (size_t)std::max(h->n_cus, 1) : (h->lat_kernel ? (size_t)std::max(h->n_cus, 1) : h->resident_wgs);
+    if (2 * (size_t)h->p.B * (h->p.nblk + 1) > slots && hipStreamQuery(h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        BN_HIP(hipStreamSynchronize(h->stream));
+    }
     BN_HIP(hipEventRecord(h->ev_fork, h->stream));                  // fork: the extra streams start behind everything enqueued so far
     for (int q = 0; q + 1 < S; ++q) BN_HIP(hipStreamWaitEvent(h->xstream[q], h->ev_fork, 0));
     int rc = BN_OK;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
-        rc = solve_impl(h, states, states_where, e, noise, false, true, (i % S) ? h->xstream[i % S - 1] : h->stream, (n - 1 - i) % S);
+        // Stream (and trajectory buffer) of solve i: round robin, except that the LAST solve always runs on the handle's own stream
+        // -- whatever follows it there (the batch's tail kernel, a getter) is then ordered by the queue itself instead of by a
+        // cross-queue event that has only just fired (measured: 18 us between the last rollout kernel and the tail).  With an
+        // even n the last two solves share the stream, which costs one overlap.  (Not the first two: the solve on the other
+        // stream would then become eligible before its predecessor is even dispatched -- see the note on eligibility above.)
+        const int q = i == n - 1 ? 0 : i % S;
+        rc = solve_impl(h, states, states_where, e, noise, false, true, q ? h->xstream[q - 1] : h->stream, q);
     }
+    // A long batch ends with its own tail, enqueued right behind the last solve and BEFORE the join: a tail kernel that comes later
+    // (flush, sync, a getter) would sit behind the join's barrier packet, ~10 us of queue processing after the last rollout kernel.
+    // Short batches keep the tail pending: chained short batches carry it in their next launch for free.
+    if (rc == BN_OK && n >= kEagerTailMinBatch && !h->in_episode) rc = flush_tail(h);
     for (int q = 0; q + 1 < S; ++q) {                               // join: the handle's stream continues behind all of them
         hipError_t e1 = hipEventRecord(h->ev_join[q], h->xstream[q]);
         hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join[q], 0);
         if (rc == BN_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(BN_ERR_HIP, "joining the overlapped launches failed");
     }
-    if (hipEventRecord(h->ev_done, h->stream) != hipSuccess && rc == BN_OK) rc = fail(BN_ERR_HIP, "hipEventRecord failed");
     return rc;
 }
 

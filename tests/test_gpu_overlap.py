@@ -132,6 +132,39 @@ def test_overlapped_episodes_log_the_same_closed_loop(K, T, B, n, corner):
             assert np.array_equal(x, y), (b, j)
 
 
+def test_big_batches_behind_pending_work_do_not_crowd_each_other_out():
+    """A waiting workgroup holds its slot, and two launches that become eligible at the same instant are not dispatched
+    fairly: the successor's waiting workgroups can take every slot before its predecessor got one.  Inside a batch that cannot
+    happen (a launch becomes eligible a whole kernel after its predecessor); at the start of a batch it could when earlier
+    work is still pending on the stream -- big launches wait for the stream there.  70 instances (more workgroups than slots)
+    behind a few milliseconds of matmuls, and two batches back to back: no wait expires, results as on one stream."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    K, T, B = 1024, 50, 70
+    inst = synth.make_instance(G, seed=21)
+    st = torch.stack([inst.start + torch.tensor([0.01 * b, 0.0, 0.0]) for b in range(B)]).cuda()
+    stream = torch.cuda.Stream()
+    big = torch.randn(2048, 2048, device="cuda")
+    torch.cuda.synchronize()
+    res = {}
+    for overlap in (False, True):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, shared_map=True, seed=5, lean=True,
+                        overlap=overlap, kernel="role", stream=stream.cuda_stream) as pl:
+            pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+            with torch.cuda.stream(stream):
+                acc = big
+                for _ in range(30):
+                    acc = (acc @ big) * 1e-3                # keeps the stream busy while the batches are enqueued
+            pl.solve_n_async_device(6, st.data_ptr())
+            pl.solve_n_async_device(7, st.data_ptr())        # behind the first batch, no sync in between
+            pl.sync()                                        # raises if a device-side wait gave up
+            res[overlap] = [(pl.costs(b), pl.weights(b), pl.get_mean(b)) for b in (0, B // 2, B - 1)]
+            assert pl.solve_count() == 13
+    for a, c in zip(res[True], res[False]):
+        for j, (a_, c_) in enumerate(zip(a, c)):
+            assert np.array_equal(a_, c_), j
+
+
 def test_two_handles_in_flight_do_not_starve_each_other():
     """Workgroups of an overlapped launch hold their slots while they wait.  Several handles doing that at once can leave no
     slot for each other's predecessors; the library lets one handle per device overlap at a time and runs the other's batch
