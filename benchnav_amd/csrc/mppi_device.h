@@ -539,7 +539,9 @@ __device__ __forceinline__ void merge_group(const float *__restrict__ part, int 
 
 // BIG = false leaves the two-level code out of callers that never see more than 64 rows (the rollout kernels'
 // prologue / aux / ticket merges): it costs them registers.
-template <int NT, bool AGENT = false, bool BIG = false>
+// SYNC = false leaves out the closing barrier: for a caller whose threads go on to use only the us[] entries they wrote
+// themselves (jj = tid, tid + NT, ...) and that has a barrier of its own before anybody reads somebody else's.
+template <int NT, bool AGENT = false, bool BIG = false, bool SYNC = true>
 __device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
                                                float *red, int tid, float &m_out, float &S_out, bool have_pre, const MergeLoads &pre)
 {
@@ -602,7 +604,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
             us[jj] = acc / S;
         }
     }
-    __syncthreads();
+    if (SYNC) __syncthreads();
     m_out = m;
     S_out = S;
 #undef BN_PLD
