@@ -58,6 +58,10 @@ bool is_pow2_float(float v)
 std::mutex g_overlap_mu;
 std::map<int, bn_mppi *> g_overlap_owner;   // device -> the handle whose overlapped batch was enqueued last
 
+// Up to this many workgroups per instance every rollout workgroup re-merges the previous solve's partials itself (pipelined mode:
+// no merge launch, no ticket round trips); above, the last workgroup of a launch merges (ticket mode).  64 = what the few-rows
+// merge takes in one wave; measured at K=4096: 17.1 us per solve pipelined against 21.2 with the ticket merge (tools/k_sweep.py).
+constexpr int kPipelinedMaxBlocks = 64;
 constexpr int kEagerTailMinBatch = 16;    // overlapped batches of at least this many solves end with their own tail kernel
 constexpr int kMaxStreams = 3;            // launches of one overlapped batch in flight at most
 constexpr int kSlots = kMaxStreams + 1;   // per-solve buffer slots (see bn_mppi::d_cost)
@@ -385,7 +389,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats; p.mean_used = h->d_mean_used;
     // every rollout workgroup re-merges the previous solve's nblk partials: only worth it while they are few
     p.slip_on = (cfg->flags & BN_FLAG_SAMPLED_SLIP) ? 1 : 0;
-    h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 32 && !p.slip_on;
+    h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= kPipelinedMaxBlocks && !p.slip_on;
     // throughput kernel: launches with more workgroups than the role kernel keeps resident in one round (4 per CU)
     h->wave_kernel = h->pipelined && want_wave;
     // latency variant: every workgroup (rollouts + aux) alone on a CU, its LDS layout must fit, not forced elsewhere

@@ -564,12 +564,21 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         for (int jj = tid; jj < 2 * T; jj += NT) {
             float acc = 0.0f;
             if (BN_VAR_SKIP & 4) { us[jj] = L.v[0] * 1e-3f; continue; }
+            // rows beyond the prefetched ones in groups of kMergePrefetch: every load of a group goes out before its first use
+            // (one at a time, each behind the previous row's FMA, 48 device-scope loads cost a K=4096 solve 13 us)
+            int i0 = 0;
             if (jj == L.j) {
 #pragma unroll
                 for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], BN_SCALE(i), acc);   // f == 0 past nblk
-                for (int i = kMergePrefetch; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), BN_SCALE(i), acc);
-            } else {
-                for (int i = 0; i < nblk; ++i) acc = __builtin_fmaf(BN_PLD((size_t)i * PS + 2 + jj), BN_SCALE(i), acc);
+                i0 = kMergePrefetch;
+            }
+            for (; i0 < nblk; i0 += kMergePrefetch) {
+                float v[kMergePrefetch];
+#pragma unroll
+                for (int q = 0; q < kMergePrefetch; ++q) v[q] = BN_PLD((size_t)min(i0 + q, nblk - 1) * PS + 2 + jj);
+#pragma unroll
+                for (int q = 0; q < kMergePrefetch; ++q)
+                    if (i0 + q < nblk) acc = __builtin_fmaf(v[q], BN_SCALE(i0 + q), acc);
             }
             us[jj] = acc / S;
         }

@@ -43,6 +43,33 @@ def test_lat_kernel_chain_equals_role_kernel_chain(K, T, B, noise, lean):
             assert np.array_equal(a_, b_), (b, j)
 
 
+@pytest.mark.parametrize("K,T,B", [(4096, 20, 1), (3000, 12, 2), (2100, 50, 1)], ids=["K4096", "K3000-B2", "K2100"])
+def test_mid_size_solves_merge_in_the_prologue_like_the_two_launch_path(K, T, B):
+    """33 to 64 workgroups per instance: every rollout workgroup re-merges the previous solve's partials itself (pipelined mode
+    and the latency kernel, rows beyond the first 16 loaded in groups) instead of the ticket merge.  Independent check: the
+    two-launch path (BN_FLAG_NO_PIPELINE: rollouts, then the tail kernel merges) over a chain of warm-started solves, overlapped
+    and on one stream."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    G, n = 256, 5
+    insts = [synth.make_instance(G, seed=50 + b, jitter=True) for b in range(B)]
+    st = torch.stack([it.start for it in insts]).cuda()
+    torch.cuda.synchronize()
+    res = {}
+    for name, kw in (("two-launch", dict(pipeline=False)), ("lat-overlap", dict(kernel="lat")), ("lat-one-stream", dict(kernel="lat", overlap=False)),
+                     ("role-overlap", dict(kernel="role"))):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, seed=3, **kw) as pl:
+            for b, it in enumerate(insts):
+                pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
+            pl.solve_n_async_device(n, st.data_ptr())
+            pl.sync()
+            res[name] = [(pl.states(b), pl.costs(b), pl.weights(b), pl.get_mean(b)) for b in range(B)]
+    for name in ("lat-overlap", "lat-one-stream", "role-overlap"):
+        for b in range(B):
+            for j, (a_, b_) in enumerate(zip(res[name][b], res["two-launch"][b])):
+                assert np.array_equal(a_, b_), (name, b, j)
+
+
 def test_lat_kernel_matches_the_oracle_and_the_reference_fixture():
     from helpers import (assert_oracle_parity, assert_within, load_case, native_outputs, native_planner_for, oracle_metrics, oracle_params_for,
                          parity_metrics)
