@@ -392,9 +392,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= kPipelinedMaxBlocks && !p.slip_on;
     // throughput kernel: launches with more workgroups than the role kernel keeps resident in one round (4 per CU)
     h->wave_kernel = h->pipelined && want_wave;
-    // latency variant: every workgroup (rollouts + aux) alone on a CU, its LDS layout must fit, not forced elsewhere
+    // latency variant: every workgroup (rollouts + aux) alone on a CU -- with room left for one instance of an overlapped successor
+    // (15 instances of K=1024 fill 255 of 256 CUs: 15.3 us per launch against the role kernel's 13.9; 14 instances 13.1 against
+    // 13.9) --, its LDS layout must fit, not forced elsewhere
     h->lat_kernel = h->pipelined && !h->wave_kernel && !(cfg->flags & BN_FLAG_ROLE_KERNEL) && bn::lat_lds_bytes(p) > 0 &&
-                    ((cfg->flags & BN_FLAG_LAT_KERNEL) || (size_t)p.B * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
+                    ((cfg->flags & BN_FLAG_LAT_KERNEL) || ((size_t)p.B + 1) * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
     if (const char *e = std::getenv("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
     alloc(&h->d_flags, ((kSlots + 1) * B + 2) * bn::kFlagStride * sizeof(unsigned long long));
     if (h->lat_kernel && p.nblk <= 16 && 2 * p.T <= bn::kRolloutThreads && !std::getenv("BN_NO_GRANULES"))
