@@ -21,7 +21,19 @@
 namespace {
 
 constexpr int kProfGroup = 10;
-constexpr size_t kWaveKernelMinWorkgroups = 1900;   // measured crossover (tools/batched_rate.py, BN_KERNEL=role|wave): between 96 and 128 instances of K=1024, overlapped or not
+// Role kernel or one-wave throughput kernel for a many-instance launch?  Both give bit-identical results; which one is faster
+// depends on the horizon (the role kernel's skeleton -- prologue, barriers, epilogue -- is a fixed cost per workgroup, the one-wave
+// kernel pays per step), on the workgroups per instance (both re-merge nblk rows per workgroup) and on how full the chip gets.
+// A two-term estimate of either kernel's time per launch, fitted to tools/auto_sweep.py (K 128..2048, T 10..100, 16..300
+// instances, overlapped launches): it picks the faster kernel or one within 10 % of it in 51 of 52 cells (worst: 28 %), where a
+// fixed workgroup-count threshold lost 14-60 % in seven.  K=1024, T=50: crossover between 64 and 128 instances as measured.
+bool wave_kernel_is_faster(const bn::SolveParams &p, size_t resident_role_wgs, int n_cus)
+{
+    const double W = (double)p.B * (p.nblk + 1), R = (double)std::max<size_t>(resident_role_wgs, 1), rows = std::max(0, p.nblk - 16);
+    const double role = (4.5 + 0.19 * p.T + 0.3 * rows) * (1.0 + 0.175 * std::min(W, R) / std::max(n_cus, 1)) * std::max(1.0, W / R);
+    const double wave = (3.3 + 0.44 * p.T + 0.37 * rows) * (1.0 + 1.5 * W / (24.0 * std::max(n_cus, 1)));
+    return wave < role;
+}
 thread_local std::string g_last_error;
 
 int fail(int code, const char *fmt, ...)
@@ -356,7 +368,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     alloc(&h->d_mean_used, B * T * 2 * 4);
     // the throughput kernel keeps its controls in this buffer instead of an LDS tile, requested or not
     const bool want_wave = !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_ROLE_KERNEL | BN_FLAG_SAMPLED_SLIP)) && p.nblk <= 32 &&
-                           ((cfg->flags & BN_FLAG_WAVE_KERNEL) || (size_t)p.B * (p.nblk + 1) > kWaveKernelMinWorkgroups);
+                           ((cfg->flags & BN_FLAG_WAVE_KERNEL) ||
+                            (((size_t)p.B + 1) * (p.nblk + 1) > (size_t)h->n_cus && wave_kernel_is_faster(p, h->resident_wgs, h->n_cus)));
     if (p.store_u || want_wave) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
     for (int q = 0; q < kSlots; ++q) {
         alloc(&h->d_cost[q], B * K * 4);

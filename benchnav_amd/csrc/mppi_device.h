@@ -541,7 +541,10 @@ __device__ __forceinline__ void merge_group(const float *__restrict__ part, int 
 // prologue / aux / ticket merges): it costs them registers.
 // SYNC = false leaves out the closing barrier: for a caller whose threads go on to use only the us[] entries they wrote
 // themselves (jj = tid, tid + NT, ...) and that has a barrier of its own before anybody reads somebody else's.
-template <int NT, bool AGENT = false, bool BIG = false, bool SYNC = true>
+// WIDE picks how the rows beyond the prefetched 16 are loaded (same arithmetic either way): sixteen at a time through a second
+// register array (kernels that own a CU: the latency kernel, the stand-alone tail), or eight at a time from one address register
+// (the role and one-wave kernels, whose occupancy hangs on ~80 VGPRs and no scratch segment: tests/test_build_artifacts.py).
+template <int NT, bool AGENT = false, bool BIG = false, bool SYNC = true, bool WIDE = false>
 __device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
                                                float *red, int tid, float &m_out, float &S_out, bool have_pre, const MergeLoads &pre)
 {
@@ -564,21 +567,50 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         for (int jj = tid; jj < 2 * T; jj += NT) {
             float acc = 0.0f;
             if (BN_VAR_SKIP & 4) { us[jj] = L.v[0] * 1e-3f; continue; }
-            // rows beyond the prefetched ones in groups of kMergePrefetch: every load of a group goes out before its first use
-            // (one at a time, each behind the previous row's FMA, 48 device-scope loads cost a K=4096 solve 13 us)
             int i0 = 0;
             if (jj == L.j) {
 #pragma unroll
                 for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], BN_SCALE(i), acc);   // f == 0 past nblk
                 i0 = kMergePrefetch;
             }
-            for (; i0 < nblk; i0 += kMergePrefetch) {
-                float v[kMergePrefetch];
+            // Rows beyond the prefetched ones with several loads in flight (one at a time, each behind the previous row's FMA, 48
+            // device-scope loads cost a K=4096 solve 13 us).  A second 16-entry array costs the role kernel 25 VGPRs, reusing the
+            // prefetch array a scratch segment, eight scalars with 64-bit addresses 8 VGPRs too many -- each 17-35 % of its
+            // throughput at four workgroups per CU (tools/config_rate.py) --, hence the two forms.
+            if constexpr (WIDE) {
+                for (; i0 < nblk; i0 += kMergePrefetch) {
+                    float v[kMergePrefetch];
 #pragma unroll
-                for (int q = 0; q < kMergePrefetch; ++q) v[q] = BN_PLD((size_t)min(i0 + q, nblk - 1) * PS + 2 + jj);
+                    for (int q = 0; q < kMergePrefetch; ++q) v[q] = BN_PLD((size_t)min(i0 + q, nblk - 1) * PS + 2 + jj);
 #pragma unroll
-                for (int q = 0; q < kMergePrefetch; ++q)
-                    if (i0 + q < nblk) acc = __builtin_fmaf(v[q], BN_SCALE(i0 + q), acc);
+                    for (int q = 0; q < kMergePrefetch; ++q)
+                        if (i0 + q < nblk) acc = __builtin_fmaf(v[q], BN_SCALE(i0 + q), acc);
+                }
+            } else {
+                for (; i0 < nblk; i0 += 8) {
+                    // one 32-bit offset from the (uniform) row base, the eight rows at constant distances: one address register
+                    const float *row = part + (unsigned)(i0 * PS + 2 + jj);
+                    const int left = nblk - i0;
+                    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f;
+    #define BN_ROW(k) (AGENT ? load_agent(row + (k) * PS) : row[(k) * PS])
+                    v0 = BN_ROW(0);
+                    if (left > 1) v1 = BN_ROW(1);
+                    if (left > 2) v2 = BN_ROW(2);
+                    if (left > 3) v3 = BN_ROW(3);
+                    if (left > 4) v4 = BN_ROW(4);
+                    if (left > 5) v5 = BN_ROW(5);
+                    if (left > 6) v6 = BN_ROW(6);
+                    if (left > 7) v7 = BN_ROW(7);
+    #undef BN_ROW
+                    acc = __builtin_fmaf(v0, BN_SCALE(i0), acc);
+                    if (left > 1) acc = __builtin_fmaf(v1, BN_SCALE(i0 + 1), acc);
+                    if (left > 2) acc = __builtin_fmaf(v2, BN_SCALE(i0 + 2), acc);
+                    if (left > 3) acc = __builtin_fmaf(v3, BN_SCALE(i0 + 3), acc);
+                    if (left > 4) acc = __builtin_fmaf(v4, BN_SCALE(i0 + 4), acc);
+                    if (left > 5) acc = __builtin_fmaf(v5, BN_SCALE(i0 + 5), acc);
+                    if (left > 6) acc = __builtin_fmaf(v6, BN_SCALE(i0 + 6), acc);
+                    if (left > 7) acc = __builtin_fmaf(v7, BN_SCALE(i0 + 7), acc);
+                }
             }
             us[jj] = acc / S;
         }
@@ -624,7 +656,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 // LDS: [ window | ustar 2T | X* 3(T+1) | scale nblk | red 32 | group rows ceil(nblk/16) x (2+2T) if nblk > 64 | sampled mode: draws, (mean, std) window ]
 // AGENT: the launch overlaps its predecessor (other stream): wait for the counters first, read what the predecessor wrote with
 // device-scope loads, write what the successor's tail reads (mean) with device-scope stores.
-template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false>
+template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false, bool WIDE = false>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
 {
@@ -673,7 +705,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         S = p.stats_prev[b * 2 + 1];
         __syncthreads();
     } else {
-        merge_partials<NT, AGENT, BIG>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
+        merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
         for (int j = tid; j < 2 * T; j += NT) {
             p.ustar[(size_t)b * 2 * T + j] = us[j];
             if (p.out_copy) p.out_copy[(size_t)b * 2 * T + j] = us[j];

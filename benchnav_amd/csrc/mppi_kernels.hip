@@ -33,7 +33,7 @@ template <int GEO, bool LDSWIN, int NT>
 __global__ __launch_bounds__(NT) void finish_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    finish_body<GEO, LDSWIN, NT, true>(p, blockIdx.x, p.part, p.cost, p.state, smem);
+    finish_body<GEO, LDSWIN, NT, true, false, true>(p, blockIdx.x, p.part, p.cost, p.state, smem);
 }
 
 // ------------------------------------------------------------------------------

@@ -1,0 +1,68 @@
+"""The built library's code objects: no scratch segment and a bounded register count for the kernels on the measured paths.
+
+A kernel with a private (scratch) segment -- even an unused emergency slot of 20 bytes that the register allocator reserves when
+scalar registers run short -- is dispatched far more slowly: round 2 saw the 64-instance launch go from 22.5 to 30 us through
+exactly that, and from 22.5 to 26.5 us through 90+ VGPRs (five instead of six waves per SIMD leave a 4-workgroups-per-CU launch
+no slack).  Both came from an innocent-looking change to the softmin merge, so the metadata is checked here (CPU: the library is
+cross-compiled for gfx950 by __graft_entry__.build())."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_metadata(so_path, tmp):
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", so_path, os.devnull])
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+    out = {}
+    for i, s in enumerate(starts):
+        blob = os.path.join(tmp, f"bundle{i}.bin")
+        with open(blob, "wb") as f:
+            f.write(data[s:(starts[i + 1] if i + 1 < len(starts) else len(data))])
+        co = os.path.join(tmp, f"co{i}.o")
+        r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={blob}", f"--output={co}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], capture_output=True, text=True)
+        if r.returncode or not os.path.exists(co) or os.path.getsize(co) == 0:
+            continue
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.private_segment_fixed_size:\s+(\d+)\s+\.sgpr_count:\s+\d+\s+\.sgpr_spill_count:\s+\d+\s+\.symbol:\s+(\S+)\.kd"
+                             r"[\s\S]*?\.vgpr_count:\s+(\d+)\s+\.vgpr_spill_count:\s+(\d+)", notes):
+            out[m.group(2)] = {"private": int(m.group(1)), "vgpr": int(m.group(3)), "vgpr_spills": int(m.group(4))}
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(f"{LLVM}/llvm-readelf") and os.path.exists(f"{LLVM}/clang-offload-bundler")), reason="ROCm LLVM tools not installed")
+def test_measured_kernels_have_no_scratch_segment_and_fit_their_occupancy(tmp_path):
+    from benchnav_amd import _capi
+    from benchnav_amd import build as b
+    _capi.load()                                      # builds the library if it is missing
+    meta = _kernel_metadata(b.LIB_PATH, str(tmp_path))
+    assert len(meta) > 60, f"only {len(meta)} kernels found in {b.LIB_PATH}"
+    # <EPS, GEO = 2 (power-of-two resolution, origin 0: every BASELINE configuration), LDS window, ...>
+    fast_paths = {
+        "latency kernel": r"rollout_lat_kernelILi[012]ELi2ELb[01]E",
+        "role kernel, pipelined": r"14rollout_kernelILi[012]ELi2ELb1ELb[01]ELb0E",
+        "role kernel, ticket merge (K > 4096)": r"14rollout_kernelILi0ELi2ELb1ELb0ELb1E",
+    }
+    for what, pat in fast_paths.items():
+        hits = {k: v for k, v in meta.items() if re.search(pat, k)}
+        assert hits, f"no kernel matches {what}"
+        bad = {k: v for k, v in hits.items() if v["private"] or v["vgpr_spills"]}
+        assert not bad, f"{what}: scratch segment / VGPR spills in {bad}"
+    # Tolerated: some variants of the one-wave and the sampled-slip kernel carry a 36-byte segment nothing accesses (the allocator's
+    # emergency slot: 100+ scalar registers of launch parameters are live across their phases).  Measured harmless there: 256
+    # instances run the same 69.7 us per launch with the variant that has it (origin 0) and the one that has not (origin != 0).
+    for pat in (r"rollout_wave_kernelILi[012]ELi2ELb1E", r"rollout_sampled_kernelILi0ELi2ELb[01]E"):
+        ks = {k: v for k, v in meta.items() if re.search(pat, k)}
+        assert ks and all(v["private"] <= 64 and v["vgpr_spills"] == 0 for v in ks.values()), ks
+    # the role kernel lives at four workgroups (20 waves) per CU: six waves per SIMD need at most 80 VGPRs (allocated in eights)
+    role = {k: v["vgpr"] for k, v in meta.items() if re.search(fast_paths["role kernel, pipelined"], k)}
+    assert max(role.values()) <= 80, role
+    wave = {k: v["vgpr"] for k, v in meta.items() if re.search(r"rollout_wave_kernelILi[012]ELi2ELb1E", k)}
+    assert max(wave.values()) <= 80, wave
