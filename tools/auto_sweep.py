@@ -9,7 +9,7 @@ torch.set_num_threads(1)
 inst = synth.make_instance(256, seed=0, resolution=0.5)
 def rate(K, T, B, **kw):
     try:
-        with NativeMPPI(horizon=T, num_samples=K, grid_size=256, resolution=0.5, num_instances=B, shared_map=True, lean=True, **kw) as pl:
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=256, resolution=0.5, num_instances=B, shared_map=True, lean=bool(int(os.environ.get("BN_LEAN", "1"))), **kw) as pl:
             pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
             st = torch.stack([inst.start] * B).cuda()
             n = max(20, min(300, int(3e4 / (B * K / 1024 * T / 50 + 10))))
