@@ -75,6 +75,7 @@ SYMBOLS = {
     "bn_mppi_dwa_candidates": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bn_mppi_dwa_buffers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bn_mppi_sync": (C.c_int, [_H]),
+    "bn_mppi_debug_expire_wait": (C.c_int, [_H]),
     "bn_mppi_flush": (C.c_int, [_H]),
     "bn_mppi_get_weights": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_get_costs": (C.c_int, [_H, C.c_int32, _FP]),

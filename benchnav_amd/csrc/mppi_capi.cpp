@@ -129,6 +129,7 @@ struct bn_mppi {
     unsigned long long tails = 0;               // host mirror of flag_tail[b]
     bool prev_published = false;                // the latest solve counted itself into flag_part (latency kernel): its successor may overlap
     bool overlap_used = false;                  // a wait could have expired since the last check of the device error word
+    bool overlap_off = false;                   // a wait DID expire once: this handle keeps to one stream from then on
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
@@ -838,7 +839,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // Device-side episodes overlap the same way (role kernel): the successor reads the state its predecessor advanced with
     // device-scope loads after its wait (64 instances: 29.6 -> 24.8 us per control step).
     const bool overlap = (h->lat_kernel || h->role_overlap) && h->n_streams > 1 && (h->d_Xalt[0] || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE &&
-                         noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending;
+                         noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending && !h->overlap_off;
     bool mine = overlap;
     if (overlap) {                                      // see g_overlap_owner
         BN_BIND(h);
@@ -1122,10 +1123,33 @@ int bn_mppi_sync(bn_mppi_t *h)
         BN_HIP(hipMemcpy(&err, h->d_flags + (kSlots + 1) * (size_t)h->p.B * bn::kFlagStride, sizeof err, hipMemcpyDeviceToHost));
         h->overlap_used = false;
         if (err) {
-            BN_HIP(hipMemset(h->d_flags + (kSlots + 1) * (size_t)h->p.B * bn::kFlagStride, 0, sizeof(unsigned long long)));
-            return fail(BN_ERR_HIP, "an overlapped launch gave up waiting for its predecessor's partials: results are invalid");
+            // The solves since the last sync are invalid.  Leave the handle usable: counters and their host mirrors back to zero (the
+            // launches that gave up did not count themselves in consistently), nothing pending, warm start as after a reset of the
+            // mean -- and one stream from now on: whatever kept a predecessor from becoming resident (another process on the GPU,
+            // most likely) may still be there.
+            for (int q = 0; q < kMaxStreams - 1; ++q)
+                if (h->xstream[q]) BN_HIP(hipStreamSynchronize(h->xstream[q]));
+            BN_HIP(hipMemset(h->d_flags, 0, ((kSlots + 1) * (size_t)h->p.B + 2) * bn::kFlagStride * sizeof(unsigned long long)));
+            for (int q = 0; q < kSlots; ++q) h->pub[q] = 0;
+            h->tails = 0;
+            h->prev_published = false;
+            h->tail_pending = false;
+            h->overlap_off = true;
+            return fail(BN_ERR_HIP, "an overlapped launch gave up waiting for its predecessor's partials: the solves since the last "
+                                    "sync are invalid; this handle runs its launches on one stream from now on");
         }
     }
+    return BN_OK;
+}
+
+int bn_mppi_debug_expire_wait(bn_mppi_t *h)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    BN_BIND(h);
+    BN_HIP(hipStreamSynchronize(h->stream));
+    const int one = 1;
+    BN_HIP(hipMemcpy(h->d_flags + (kSlots + 1) * (size_t)h->p.B * bn::kFlagStride, &one, sizeof one, hipMemcpyHostToDevice));
+    h->overlap_used = true;
     return BN_OK;
 }
 

@@ -265,6 +265,10 @@ int bn_mppi_dwa_forward_async(bn_mppi_t *h, const float *states_device, float *p
                               float lookahead, float *best_states_device);
 int bn_mppi_dwa_candidates(bn_mppi_t *h, int32_t num_actions, const float **actions_device, const float **stage_goal_device);
 int bn_mppi_sync(bn_mppi_t *h);
+/* Test hook: mark the latest overlapped batch as if one of its bounded device-side waits had expired (what happens when another
+ * process keeps a launch's predecessor from becoming resident for ~2 s).  The next bn_mppi_sync reports BN_ERR_HIP, resets the
+ * launch counters and keeps the handle on one stream from then on. */
+int bn_mppi_debug_expire_wait(bn_mppi_t *h);
 /* Enqueue the pending tail (if any) without waiting. */
 int bn_mppi_flush(bn_mppi_t *h);
 

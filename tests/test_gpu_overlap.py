@@ -165,6 +165,37 @@ def test_big_batches_behind_pending_work_do_not_crowd_each_other_out():
             assert np.array_equal(a_, c_), j
 
 
+def test_an_expired_wait_is_reported_once_and_leaves_a_working_one_stream_handle():
+    """A bounded device-side wait that expires (another process keeping a predecessor off the chip) makes sync() raise; the
+    handle then resets its launch counters, drops the pending tail and keeps to one stream.  With the test hook: after the
+    error and a fresh warm start the handle computes what a handle that never overlapped computes (injected noise, so the
+    number of solves that went before does not matter)."""
+    import torch
+    from benchnav_amd import _capi, synth
+    K, T, B, n = 1024, 50, 2, 6
+    insts = [synth.make_instance(G, seed=60 + b) for b in range(B)]
+    st = torch.stack([it.start for it in insts]).cuda()
+    eps = np.random.default_rng(12).standard_normal((n, B, K, T, 2)).astype(np.float32)
+    ed = torch.from_numpy(eps).cuda()
+    torch.cuda.synchronize()
+    run = lambda pl: pl.solve_n_async_device(n, st.data_ptr(), ed.data_ptr(), _capi.BN_NOISE_DEVICE_KT2, n, eps[0].size)
+    with _make(K, T, B, insts, False) as ref:
+        run(ref)
+        want = _outputs(ref, B, T)
+    with _make(K, T, B, insts, True) as pl:
+        run(pl)
+        _capi.check(pl._lib.bn_mppi_debug_expire_wait(pl._h))
+        with pytest.raises(_capi.BenchnavError, match="gave up waiting"):
+            pl.sync()
+        pl.sync()                                            # reported once
+        pl.set_mean()                                        # fresh warm start (zeros), every instance
+        run(pl)                                              # one stream now
+        got = _outputs(pl, B, T)
+    for b in range(B):
+        for j, (a_, c_) in enumerate(zip(got[b], want[b])):
+            assert np.array_equal(a_, c_), (b, j)
+
+
 def test_two_handles_in_flight_do_not_starve_each_other():
     """Workgroups of an overlapped launch hold their slots while they wait.  Several handles doing that at once can leave no
     slot for each other's predecessors; the library lets one handle per device overlap at a time and runs the other's batch
