@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -69,6 +72,27 @@ bool is_pow2_float(float v)
 // device (its streams still busy); otherwise this batch runs in one stream, which is always safe.
 std::mutex g_overlap_mu;
 std::map<int, bn_mppi *> g_overlap_owner;   // device -> the handle whose overlapped batch was enqueued last
+// ... and one PROCESS per device for launches big enough to crowd each other out: two processes with overlapped 64-instance batches
+// on one GPU both ran into expired waits within a second.  An advisory lock on a per-device file in /tmp, taken (non-blocking) by
+// the first process that overlaps big launches there and held until it exits; a process that does not get it runs those batches
+// on one stream and asks again at its next batch.
+std::map<int, int> g_overlap_lock_fd;       // device -> fd holding the lock (-1: not held)
+
+bool own_device_for_big_overlap(int device)
+{
+    auto it = g_overlap_lock_fd.find(device);
+    if (it != g_overlap_lock_fd.end() && it->second >= 0) return true;
+    char bus[64] = "unknown";
+    (void)hipDeviceGetPCIBusId(bus, (int)sizeof bus, device);
+    for (char *c = bus; *c; ++c)
+        if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+    const std::string path = std::string("/tmp/benchnav_mppi_overlap_") + bus + ".lock";
+    const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) return true;                 // no lock file possible (read-only /tmp): behave as a lone process
+    if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); return false; }
+    g_overlap_lock_fd[device] = fd;
+    return true;
+}
 
 // Up to this many workgroups per instance every rollout workgroup re-merges the previous solve's partials itself (pipelined mode:
 // no merge launch, no ticket round trips); above, the last workgroup of a launch merges (ticket mode).  64 = what the few-rows
@@ -851,6 +875,8 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
             (void)hipGetLastError();
             if (busy) mine = false;
         }
+        const size_t slots_ = h->wave_kernel ? 24 * (size_t)std::max(h->n_cus, 1) : (h->lat_kernel ? (size_t)std::max(h->n_cus, 1) : h->resident_wgs);
+        if (mine && 2 * (size_t)h->p.B * (h->p.nblk + 1) > slots_ && !own_device_for_big_overlap(h->cfg.device_id)) mine = false;
         if (mine) owner = h;
     }
     if (!mine) {
