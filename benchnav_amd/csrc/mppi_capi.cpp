@@ -896,12 +896,16 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // went out); if earlier work is still pending, solves 0 and 1 would become eligible together, so launches big enough to
     // crowd each other out wait for the stream first.
     const size_t slots = h->wave_kernel ? 24 * (size_t)std::max(h->n_cus, 1) : (h->lat_kernel ? (size_t)std::max(h->n_cus, 1) : h->resident_wgs);
-    if (2 * (size_t)h->p.B * (h->p.nblk + 1) > slots && hipStreamQuery(h->stream) != hipSuccess) {
-        (void)hipGetLastError();
+    bool idle = hipStreamQuery(h->stream) == hipSuccess;
+    (void)hipGetLastError();
+    if (!idle && 2 * (size_t)h->p.B * (h->p.nblk + 1) > slots) {
         BN_HIP(hipStreamSynchronize(h->stream));
+        idle = true;
     }
-    BN_HIP(hipEventRecord(h->ev_fork, h->stream));                  // fork: the extra streams start behind everything enqueued so far
-    for (int q = 0; q + 1 < S; ++q) BN_HIP(hipStreamWaitEvent(h->xstream[q], h->ev_fork, 0));
+    if (!idle) {                                                    // fork: the extra streams start behind everything enqueued so far
+        BN_HIP(hipEventRecord(h->ev_fork, h->stream));              // (nothing is: no event packet in front of the first launches)
+        for (int q = 0; q + 1 < S; ++q) BN_HIP(hipStreamWaitEvent(h->xstream[q], h->ev_fork, 0));
+    }
     int rc = BN_OK;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
