@@ -185,6 +185,7 @@ def main():
         pl.flush()
         sync_()
         wall = time.perf_counter() - t0
+        pl.sync()            # outside the timed region: the library's own synchronisation point (checks the overlapped launches' error word)
         return wall, (e0.elapsed_time(e1) if events else None)
 
     def settle(make, state_dev, eps_ring, kind, warmup, tries=3):

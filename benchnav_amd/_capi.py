@@ -27,7 +27,7 @@ BN_FLAG_LEAN = 512
 BN_FLAG_LAT_KERNEL = 1024
 BN_FLAG_NO_OVERLAP = 2048
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Config(C.Structure):
@@ -75,6 +75,7 @@ SYMBOLS = {
     "bn_mppi_dwa_candidates": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bn_mppi_dwa_buffers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bn_mppi_sync": (C.c_int, [_H]),
+    "bn_mppi_recovery_count": (C.c_uint64, [_H]),
     "bn_mppi_debug_expire_wait": (C.c_int, [_H]),
     "bn_mppi_flush": (C.c_int, [_H]),
     "bn_mppi_get_weights": (C.c_int, [_H, C.c_int32, _FP]),
@@ -134,6 +135,20 @@ def _preload_hip_runtime():
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
+def _open_checked(path):
+    """dlopen + bind every symbol of SYMBOLS.  Returns (lib, None) or (lib, what does not match)."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            return lib, f"symbol {name} missing: the header and the library disagree"
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bn_mppi_abi_version() != ABI_VERSION:
+        return lib, f"ABI version {lib.bn_mppi_abi_version()} != binding {ABI_VERSION}"
+    return lib, None
+
+
 def load(build_if_missing: bool = True):
     """dlopen the in-tree library (building it with hipcc first if it is absent)."""
     global _lib
@@ -141,21 +156,24 @@ def load(build_if_missing: bool = True):
         return _lib
     path = lib_path()
     _preload_hip_runtime()
-    # A missing library is built; a library older than its sources is rebuilt only on request (BENCHNAV_REBUILD_IF_STALE=1):
-    # file times do not survive every way a tree gets copied to a GPU box, and a spurious 30 s rebuild in every test
-    # process would be worse than the stale-binary risk the ABI-version check below already bounds.
+    # A missing library is built.  A library older than its sources is rebuilt only on request (BENCHNAV_REBUILD_IF_STALE=1):
+    # file times do not survive every way a tree gets copied to a GPU box, and a spurious 60 s rebuild in every test
+    # process would be worse than the stale-binary risk.  A library that does not MATCH this binding -- another ABI version,
+    # or a symbol of include/benchnav_mppi.h missing -- is rebuilt once, whatever its file time says.
     stale = os.environ.get("BENCHNAV_REBUILD_IF_STALE") == "1" and _build.is_stale()
     if not os.path.exists(path) or stale:
         if not build_if_missing:
             raise RuntimeError(f"{path} is missing; run `python -m benchnav_amd.build`")
         _build.build_library()
-    lib = C.CDLL(path)
-    for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)          # AttributeError = the header and the library disagree
-        fn.restype = res
-        fn.argtypes = args
-    if lib.bn_mppi_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"ABI version mismatch: library {lib.bn_mppi_abi_version()} != binding {ABI_VERSION}")
+    lib, why = _open_checked(path)
+    if why and build_if_missing:
+        import _ctypes
+        _ctypes.dlclose(lib._handle)     # or the next dlopen of this path returns the old image
+        del lib
+        _build.build_library(force=True)
+        lib, why = _open_checked(path)
+    if why:
+        raise RuntimeError(f"{path} does not match this binding ({why}); run `python -m benchnav_amd.build`")
     _lib = lib
     return lib
 

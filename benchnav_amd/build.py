@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libbenchnav_mppi.so")
 # one translation unit per kernel family: they compile in parallel (the role kernel alone is 72 template instances)
 SOURCES = ["rollout_role_philox.hip", "rollout_role_kt2.hip", "rollout_role_t2k.hip", "rollout_wave.hip", "rollout_sampled.hip",
            "mppi_kernels.hip", "mppi_capi.cpp", "risk_kernels.hip"]
-HEADERS = ["mppi_kernels.h", "mppi_device.h", "rollout_role.inc", "bn_device_math.h", os.path.join("..", "..", "include", "benchnav_mppi.h")]
+# every header / include file under csrc/ (globbed: a new .inc cannot be forgotten here) + the public header
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "benchnav_mppi.h")]
 
 # -ffp-contract=off: the arithmetic spec fixes where FMAs are (explicit __builtin_fmaf only).
 # Division and sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).

@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cerrno>
+#include <sys/stat.h>
 #include <fcntl.h>
 #include <sys/file.h>
 #include <unistd.h>
@@ -87,8 +89,11 @@ bool own_device_for_big_overlap(int device)
     for (char *c = bus; *c; ++c)
         if (*c == ':' || *c == '.' || *c == '/') *c = '_';
     const std::string path = std::string("/tmp/benchnav_mppi_overlap_") + bus + ".lock";
-    const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    if (fd < 0) return true;                 // no lock file possible (read-only /tmp): behave as a lone process
+    // Read-only open (flock works on it): a file another user created 0644 still opens; no symlink followed in a world-writable
+    // directory.  The creator widens the mode past its umask so the next user can do the same.
+    const int fd = open(path.c_str(), O_CREAT | O_RDONLY | O_NOFOLLOW | O_CLOEXEC, 0666);
+    if (fd < 0) return errno == EROFS || errno == ENOENT;   // no lock file POSSIBLE: behave as a lone process; anything else (EACCES, ELOOP ...): do not overlap
+    (void)fchmod(fd, 0666);
     if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); return false; }
     g_overlap_lock_fd[device] = fd;
     return true;
@@ -152,8 +157,20 @@ struct bn_mppi {
     unsigned long long pub[kSlots] = {};     // host mirror: what flag_part[slot][b] reaches once every launch issued so far has published
     unsigned long long tails = 0;               // host mirror of flag_tail[b]
     bool prev_published = false;                // the latest solve counted itself into flag_part (latency kernel): its successor may overlap
-    bool overlap_used = false;                  // a wait could have expired since the last check of the device error word
+    bool overlap_used = false;                  // a wait could have expired since the last check of the error word
     bool overlap_off = false;                   // a wait DID expire once: this handle keeps to one stream from then on
+    // The error word of the bounded device-side waits: pinned host memory the kernels write with a system-scope store, so every
+    // entry point can look at it for free.  Journal: the batches enqueued since the word was last found clean at a
+    // synchronisation point, with the mean the first of them started from (kept by that launch itself, SolveParams::mean_snap)
+    // and the solve counter (= Philox position) at that point -- what recover_overlap() needs to run them again on one stream.
+    int *h_err = nullptr, *d_err = nullptr;     // host address / device address of the same word
+    float *d_mean_snap = nullptr;
+    struct BatchRec { int32_t n; const float *states; const float *eps; bn_noise_kind noise; int32_t eps_ring; int64_t eps_stride; bool episode; const float *z; };
+    std::vector<BatchRec> journal;
+    bool journal_lost = false;                  // something not replayable happened since the last clean check (or too many batches)
+    bool arm_snap = false;                      // the next launch keeps its mean in d_mean_snap
+    bool replaying = false, last_batch_overlapped = false;
+    uint64_t journal_solves0 = 0, recoveries = 0;
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
@@ -259,6 +276,98 @@ int check_instance(const bn_mppi *h, int32_t instance, bool allow_all)
     if (instance < 0 || instance >= h->p.B)
         return fail(BN_ERR_INVALID, "instance %d out of range [0,%d)", instance, h->p.B);
     return BN_OK;
+}
+
+constexpr size_t kJournalCap = 4096;
+
+void journal_push(bn_mppi *h, const bn_mppi::BatchRec &r, bool replayable)
+{
+    if (h->replaying) return;
+    if (!h->last_batch_overlapped && h->journal.empty()) return;      // nothing in flight that a wait could have spoilt
+    if (!replayable || h->journal.size() >= kJournalCap) { h->journal_lost = true; h->journal.clear(); return; }
+    if (!h->journal_lost) h->journal.push_back(r);
+}
+
+// A bounded device-side wait of an overlapped launch expired: that launch computed on incomplete partials, and every solve
+// warm-started from it since is invalid as well.  Bring the handle to rest, forget the counters, and run the journalled batches
+// again on ONE stream from the mean the first of them started from: same inputs (the callers' state / noise buffers, which must
+// stay valid until the synchronisation point that follows a batch, as for any asynchronous call), same Philox positions, hence
+// the results the overlapped launches would have produced.  The handle keeps to one stream from then on: whatever kept a
+// predecessor from becoming resident (another process on the GPU, most likely) may still be there.
+// BN_OK with a warning in bn_last_error() when the re-run succeeded (bn_mppi_recovery_count counts them: consumers enqueued
+// in stream order BEFORE this synchronisation point have read invalid buffers); BN_ERR_HIP when there was nothing to re-run from.
+int recover_overlap(bn_mppi *h)
+{
+    for (int q = 0; q < kMaxStreams - 1; ++q)
+        if (h->xstream[q]) BN_HIP(hipStreamSynchronize(h->xstream[q]));
+    BN_HIP(hipStreamSynchronize(h->stream));
+    BN_HIP(hipMemset(h->d_flags, 0, ((kSlots + 1) * (size_t)h->p.B + 2) * bn::kFlagStride * sizeof(unsigned long long)));
+    for (int q = 0; q < kSlots; ++q) h->pub[q] = 0;
+    h->tails = 0;
+    h->prev_published = false;
+    h->tail_pending = false;
+    h->overlap_off = true;
+    h->overlap_used = false;
+    h->arm_snap = false;
+    h->in_episode = false;
+    *h->h_err = 0;
+    std::vector<bn_mppi::BatchRec> recs;
+    recs.swap(h->journal);
+    const bool lost = h->journal_lost || recs.empty();
+    h->journal_lost = false;
+    if (lost)
+        return fail(BN_ERR_HIP, "an overlapped launch gave up waiting for its predecessor's partials and the batches since the last "
+                                "synchronisation point cannot be re-run: their results are invalid; this handle runs its launches on one "
+                                "stream from now on");
+    BN_HIP(hipMemcpy(h->d_mean, h->d_mean_snap, (size_t)h->p.B * h->p.T * 2 * 4, hipMemcpyDeviceToDevice));
+    h->solves = h->journal_solves0;
+    h->replaying = true;
+    int rc = BN_OK;
+    for (const auto &r : recs) {
+        rc = r.episode ? bn_mppi_episode_async(h, r.n, r.states, BN_MEM_DEVICE, r.eps, r.noise, r.eps_ring, r.eps_stride, r.z)
+                       : bn_mppi_solve_n_async(h, r.n, r.states, BN_MEM_DEVICE, r.eps, r.noise, r.eps_ring, r.eps_stride);
+        if (rc != BN_OK) break;
+    }
+    if (rc == BN_OK) rc = flush_tail(h);
+    h->replaying = false;
+    if (rc != BN_OK) return rc;
+    BN_HIP(hipStreamSynchronize(h->stream));
+    h->recoveries += 1;
+    (void)fail(BN_OK, "warning: an overlapped launch gave up waiting for its predecessor's partials; %zu batch(es) were re-run on one "
+                      "stream (results are valid now; this handle no longer overlaps its launches)", recs.size());
+    return BN_OK;
+}
+
+// The handle's stream has just been synchronised (`synced`), or the caller only wants to know what has ALREADY gone wrong:
+// look at the error word, repair if it is set.
+int settle_overlap(bn_mppi *h, bool synced)
+{
+    if (!h->overlap_used || h->replaying) return BN_OK;
+    if (__atomic_load_n(h->h_err, __ATOMIC_ACQUIRE) == 0) {
+        if (synced) {
+            bool idle = true;                                  // the extra streams are joined into the handle's stream; make sure
+            for (int q = 0; idle && q + 1 < h->n_streams; ++q) idle = hipStreamQuery(h->xstream[q]) == hipSuccess;
+            (void)hipGetLastError();
+            if (idle) { h->overlap_used = false; h->journal.clear(); h->journal_lost = false; }
+        }
+        return BN_OK;
+    }
+    return recover_overlap(h);
+}
+
+int sync_checked(bn_mppi *h)
+{
+    BN_HIP(hipStreamSynchronize(h->stream));
+    return settle_overlap(h, true);
+}
+
+// Entry points that hand results to the host, change the planner's inputs, or enqueue work the journal does not describe: whatever
+// an expired wait could have spoilt is repaired first.  Free unless overlapped launches are outstanding (then: one synchronisation).
+int settle_point(bn_mppi *h)
+{
+    if (!h->overlap_used || h->replaying) return BN_OK;
+    if (int rc = flush_tail(h)) return rc;
+    return sync_checked(h);
 }
 
 }  // namespace
@@ -437,6 +546,12 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
                     ((cfg->flags & BN_FLAG_LAT_KERNEL) || ((size_t)p.B + 1) * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
     if (const char *e = std::getenv("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
     alloc(&h->d_flags, ((kSlots + 1) * B + 2) * bn::kFlagStride * sizeof(unsigned long long));
+    alloc(&h->d_mean_snap, B * T * 2 * 4);
+    if (rc == BN_OK) {
+        if (hipHostMalloc((void **)&h->h_err, 64, hipHostMallocMapped) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostMalloc (error word) failed");
+        else if (hipHostGetDevicePointer((void **)&h->d_err, h->h_err, 0) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostGetDevicePointer failed");
+        else *h->h_err = 0;
+    }
     if (h->lat_kernel && p.nblk <= 16 && 2 * p.T <= bn::kRolloutThreads && !std::getenv("BN_NO_GRANULES"))
         for (int q = 0; q < kSlots; ++q) alloc(&h->d_gran[q], (B * (size_t)p.nblk * (2 + 2 * T) + 4 * B) * sizeof(unsigned long long));   // rows, then 4 per instance for the state
     // the role kernel (launches that do not leave every workgroup a CU of its own) overlaps its launches as well: a workgroup of
@@ -525,6 +640,8 @@ void bn_mppi_destroy(bn_mppi_t *h)
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->h_err) (void)hipHostFree(h->h_err);
+    if (h->d_mean_snap) (void)hipFree(h->d_mean_snap);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -534,6 +651,7 @@ int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_ki
     if (int rc = check_instance(h, instance, true)) return rc;
     if (!risk) return fail(BN_ERR_INVALID, "risk is null");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     const size_t bytes = (size_t)h->p.G * h->p.G * 4;
     const hipMemcpyKind kind = where == BN_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const int lo = instance < 0 ? 0 : std::min(instance, h->n_maps - 1);
@@ -551,6 +669,7 @@ int bn_mppi_set_slip_std(bn_mppi_t *h, int32_t instance, const float *stdv, bn_m
     if (!stdv) return fail(BN_ERR_INVALID, "std is null");
     if (!h->p.slip_on) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_SAMPLED_SLIP");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t bytes = (size_t)h->p.G * h->p.G * 4;
@@ -576,6 +695,7 @@ int bn_mppi_set_goal(bn_mppi_t *h, int32_t instance, const float goal_host[2])
     if (int rc = check_instance(h, instance, true)) return rc;
     if (!goal_host) return fail(BN_ERR_INVALID, "goal is null");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const int lo = instance < 0 ? 0 : instance, hi = instance < 0 ? h->p.B : instance + 1;
@@ -588,6 +708,7 @@ int bn_mppi_set_mean(bn_mppi_t *h, int32_t instance, const float *mean_host)
 {
     if (int rc = check_instance(h, instance, true)) return rc;
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;           // afterwards the mean buffer is authoritative again
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->p.T * 2;
@@ -604,6 +725,7 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!mean_host) return fail(BN_ERR_INVALID, "null output");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t n = (size_t)h->p.T * 2;
@@ -716,7 +838,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         }
         if ((h->lat_kernel || h->role_overlap) && overlap) {   // member of an overlapped batch: publishes, and waits if its predecessor published
             p.flag_part = h->d_flags;
-            p.err = reinterpret_cast<int *>(h->d_flags + (kSlots + 1) * B * bn::kFlagStride);
+            p.err = h->d_err;                                          // pinned host memory, mapped
+            if (h->arm_snap) { p.mean_snap = h->d_mean_snap; h->arm_snap = false; }
             p.cur_slot = cur3; p.prev_slot = prev3;
             p.wait_part = h->pub[prev3];
             p.gran = p.lat_kernel ? h->d_gran[cur3] : nullptr;
@@ -784,6 +907,11 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
 int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
                         bn_noise_kind noise)
 {
+    if (h && !h->replaying && !h->journal.empty()) {
+        // a single solve behind overlapped batches whose error word has not been checked yet: journalled as a batch of one
+        h->last_batch_overlapped = false;
+        journal_push(h, bn_mppi::BatchRec{1, states, eps, noise, 1, 0, false, nullptr}, states_where == BN_MEM_DEVICE && noise != BN_NOISE_HOST_KT2);
+    }
     return solve_impl(h, states, states_where, eps, noise, false);
 }
 
@@ -791,6 +919,11 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
 {
     // MPPI.forward as ONE call for a host loop that consumes every solve's outputs (test_mppi.py:174-183): the solve and
     // its tail, both only enqueued; U*, X*, weights are in the device buffers in stream order.
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    {
+        BN_BIND(h);
+        if (int rc = settle_point(h)) return rc;       // behind overlapped batches: those are checked (one synchronisation) first
+    }
     if (int rc = solve_impl(h, states_device, BN_MEM_DEVICE, eps_device, noise, false)) return rc;
     BN_BIND(h);
     if (!h->tail_pending && out_device) {              // two-launch modes: the tail has run; one small copy on the stream
@@ -806,6 +939,7 @@ int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout)
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (first_rollout < 0 || first_rollout + h->p.K > 0x7fffffffLL) return fail(BN_ERR_INVALID, "first_rollout out of range");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     h->p.k0 = (int)first_rollout;
     return BN_OK;
@@ -836,6 +970,7 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
     if (!h->shard_pending) return fail(BN_ERR_STATE, "no sharded solve in flight");
     if (!all_partials_device || total_workgroups < h->p.nblk) return fail(BN_ERR_INVALID, "need the partials of every shard");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     bn::SolveParams p = h->p;
     const int cur = (int)((h->solves - 1) % kSlots);
     p.solve = p.tail_solve = h->solves - 1;
@@ -879,14 +1014,23 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         if (mine && 2 * (size_t)h->p.B * (h->p.nblk + 1) > slots_ && !own_device_for_big_overlap(h->cfg.device_id)) mine = false;
         if (mine) owner = h;
     }
+    const bn_mppi::BatchRec rec{n, states, eps, noise, eps_ring, eps_stride, false, nullptr};
+    const bool replayable = states_where == BN_MEM_DEVICE && noise != BN_NOISE_HOST_KT2;
     if (!mine) {
+        h->last_batch_overlapped = false;
         for (int32_t i = 0; i < n; ++i) {
             const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
-            if (int rc = bn_mppi_solve_async(h, states, states_where, e, noise)) return rc;
+            if (int rc = solve_impl(h, states, states_where, e, noise, false)) return rc;
         }
+        if (!h->in_episode) journal_push(h, rec, replayable);   // behind an overlapped batch not yet checked: lost with it, re-run with it
         return BN_OK;
     }
     BN_BIND(h);
+    h->last_batch_overlapped = true;
+    if (!h->replaying && h->journal.empty() && !h->journal_lost) {   // first batch since the error word was last seen clean
+        h->journal_solves0 = h->solves;
+        h->arm_snap = true;
+    }
     const int S = h->n_streams;
     // The scheme relies on a launch having been dispatched before its successor becomes eligible: waiting workgroups hold their
     // slots, and the hardware does not share freed slots fairly between two queues (seen with two 70-instance launches made
@@ -926,6 +1070,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join[q], 0);
         if (rc == BN_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(BN_ERR_HIP, "joining the overlapped launches failed");
     }
+    if (rc == BN_OK && !h->in_episode) journal_push(h, rec, replayable);
     return rc;
 }
 
@@ -935,6 +1080,7 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
     if (!h || !latent_mean || !latent_std) return fail(BN_ERR_INVALID, "null argument");
     if (!(goal_threshold >= 0.0f) || !(delta_t > 0.0f)) return fail(BN_ERR_INVALID, "goal_threshold >= 0 and delta_t > 0 required");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t bytes = (size_t)h->n_maps * h->p.G * h->p.G * 4;
@@ -967,6 +1113,7 @@ int bn_mppi_env_set_freeze(bn_mppi_t *h, int32_t freeze_on_goal)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     h->p.env_freeze = freeze_on_goal ? 1 : 0;
     return BN_OK;
@@ -978,6 +1125,7 @@ int bn_mppi_env_step(bn_mppi_t *h, const float *actions_device, float *states_de
     if (!h || !actions_device || !states_device || !rewards_device || !terminated_device) return fail(BN_ERR_INVALID, "null argument");
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_step");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     BN_HIP(bn::launch_env_step(h->p, actions_device, states_device, rewards_device, terminated_device, z_device, step_index, h->stream));
     return BN_OK;
 }
@@ -989,6 +1137,7 @@ int bn_mppi_env_collision_check(bn_mppi_t *h, const float *states_device, int32_
     if (n_positions < 1) return fail(BN_ERR_INVALID, "n_positions must be >= 1");
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_collision_check");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     BN_HIP(bn::launch_env_collision(h->p, states_device, n_positions, stuck_threshold, z_device, draw_index, out_device, h->stream));
     return BN_OK;
 }
@@ -1029,6 +1178,7 @@ int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, b
     int rc = bn_mppi_solve_n_async(h, n_steps, states0, states_where, eps, noise, eps_ring, eps_stride);
     if (rc == BN_OK) rc = flush_tail(h);              // the last solve's tail and the last environment step
     h->in_episode = false;
+    if (rc == BN_OK) journal_push(h, bn_mppi::BatchRec{n_steps, states0, eps, noise, eps_ring, eps_stride, true, z_device}, noise != BN_NOISE_HOST_KT2);
     return rc;
 }
 
@@ -1037,6 +1187,7 @@ int bn_mppi_episode_log(bn_mppi_t *h, float *states_host, float *rewards_host, f
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->d_ep_states || h->ep_len < 1) return fail(BN_ERR_STATE, "no episode has been run");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t B = h->p.B, n = (size_t)h->ep_len;
     if (states_host) BN_HIP(hipMemcpy(states_host, h->d_ep_states, (n + 1) * B * 3 * 4, hipMemcpyDeviceToHost));
@@ -1054,6 +1205,7 @@ int bn_mppi_dwa_solve(bn_mppi_t *h, const float *states_host, const float *actio
     if (num_actions < 1 || num_actions > 1024) return fail(BN_ERR_INVALID, "num_actions must be in [1, 1024]");
     if (!h->map_set || !h->goal_set) return fail(BN_ERR_STATE, "set_map and set_goal must precede dwa_solve");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     const size_t B = h->p.B, NA = num_actions, T1 = h->p.T + 1;
     // scratch layout: actions | stage goal | X | cost | w | best | best states | states
@@ -1098,6 +1250,7 @@ int bn_mppi_dwa_forward_async(bn_mppi_t *h, const float *states_device, float *p
     if (path_device && num_path < 1) return fail(BN_ERR_INVALID, "a reference path needs at least one point");
     if (!h->map_set || !h->goal_set) return fail(BN_ERR_STATE, "set_map and set_goal must precede dwa_forward");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     const size_t B = h->p.B, T1 = h->p.T + 1;
     // the scratch layout of bn_mppi_dwa_solve: actions | stage goal | X | cost | w | best | best states | states
@@ -1147,38 +1300,32 @@ int bn_mppi_sync(bn_mppi_t *h)
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
-    BN_HIP(hipStreamSynchronize(h->stream));
-    if (h->overlap_used) {                             // a bounded device-side wait of an overlapped launch may have expired
-        int err = 0;
-        BN_HIP(hipMemcpy(&err, h->d_flags + (kSlots + 1) * (size_t)h->p.B * bn::kFlagStride, sizeof err, hipMemcpyDeviceToHost));
-        h->overlap_used = false;
-        if (err) {
-            // The solves since the last sync are invalid.  Leave the handle usable: counters and their host mirrors back to zero (the
-            // launches that gave up did not count themselves in consistently), nothing pending, warm start as after a reset of the
-            // mean -- and one stream from now on: whatever kept a predecessor from becoming resident (another process on the GPU,
-            // most likely) may still be there.
-            for (int q = 0; q < kMaxStreams - 1; ++q)
-                if (h->xstream[q]) BN_HIP(hipStreamSynchronize(h->xstream[q]));
-            BN_HIP(hipMemset(h->d_flags, 0, ((kSlots + 1) * (size_t)h->p.B + 2) * bn::kFlagStride * sizeof(unsigned long long)));
-            for (int q = 0; q < kSlots; ++q) h->pub[q] = 0;
-            h->tails = 0;
-            h->prev_published = false;
-            h->tail_pending = false;
-            h->overlap_off = true;
-            return fail(BN_ERR_HIP, "an overlapped launch gave up waiting for its predecessor's partials: the solves since the last "
-                                    "sync are invalid; this handle runs its launches on one stream from now on");
-        }
-    }
-    return BN_OK;
+    return sync_checked(h);            // a bounded device-side wait of an overlapped launch may have expired: see recover_overlap
 }
+
+uint64_t bn_mppi_recovery_count(const bn_mppi_t *h) { return h ? h->recoveries : 0; }
 
 int bn_mppi_debug_expire_wait(bn_mppi_t *h)
 {
+    // Test hook: behave as if a wait had expired in the batches enqueued since the last synchronisation point -- the error word is
+    // set and everything those batches wrote (mean, U* | X*, weights, costs, trajectories) is overwritten with NaN patterns, so a
+    // caller that gets valid results afterwards got them from the re-run.
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
+    if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
-    const int one = 1;
-    BN_HIP(hipMemcpy(h->d_flags + (kSlots + 1) * (size_t)h->p.B * bn::kFlagStride, &one, sizeof one, hipMemcpyHostToDevice));
+    const size_t B = h->p.B, K = h->p.K, T = h->p.T;
+    BN_HIP(hipMemset(h->d_mean, 0xff, B * T * 2 * 4));
+    BN_HIP(hipMemset(h->d_ustar, 0xff, (B * T * 2 + B * (T + 1) * 3) * 4));
+    BN_HIP(hipMemset(h->d_w, 0xff, B * K * 4));
+    BN_HIP(hipMemset(h->d_cost_out, 0xff, B * K * 4));
+    if (h->d_X) BN_HIP(hipMemset(h->d_X, 0xff, B * (T + 1) * 3 * (size_t)h->p.Kp * 4));
+    if (h->d_ep_states && h->ep_len > 0) {
+        BN_HIP(hipMemset(h->d_ep_states, 0xff, (size_t)(h->ep_len + 1) * B * 3 * 4));
+        BN_HIP(hipMemset(h->d_ep_reward, 0xff, (size_t)h->ep_len * B * 4));
+        BN_HIP(hipMemset(h->d_ep_action, 0xff, (size_t)h->ep_len * B * 2 * 4));
+    }
+    *h->h_err = 1;
     h->overlap_used = true;
     return BN_OK;
 }
@@ -1187,12 +1334,17 @@ int bn_mppi_flush(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
-    return flush_tail(h);
+    if (int rc = flush_tail(h)) return rc;
+    // no synchronisation here; but an expiry that has ALREADY happened is repaired now rather than at the next synchronising call
+    return (h->overlap_used && !h->replaying && __atomic_load_n(h->h_err, __ATOMIC_ACQUIRE)) ? settle_overlap(h, false) : BN_OK;
 }
 
 int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps,
                   bn_noise_kind noise, float *ustar_host, float *xstar_host)
 {
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = bn_mppi_solve_async(h, states, states_where, eps, noise)) return rc;
     if (int rc = flush_tail(h)) return rc;
     const size_t B = h->p.B, T = h->p.T;
@@ -1227,6 +1379,7 @@ int bn_mppi_reroll_async(bn_mppi_t *h, int32_t instance, const int32_t *idx_devi
     if (n == 0) return BN_OK;
     if (!out_device) return fail(BN_ERR_INVALID, "null output");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     return reroll_rows(h, instance, idx_device, n, out_device);
 }
 
@@ -1235,6 +1388,7 @@ static int copy_out(bn_mppi_t *h, int32_t instance, const float *dev, size_t per
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     BN_HIP(hipMemcpy(out_host, dev + (size_t)instance * per_instance, per_instance * 4, hipMemcpyDeviceToHost));
@@ -1256,6 +1410,7 @@ int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host)
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     const size_t K = h->p.K, Kp = h->p.Kp, T1 = h->p.T + 1, n = K * T1 * 3;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
     if (h->p.lean) {                                   // not materialised: regenerate all K rows
@@ -1274,6 +1429,7 @@ int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host)
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     if (!h->d_U || !h->p.store_u) return fail(BN_ERR_STATE, "controls are only stored with BN_FLAG_STORE_CONTROLS");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     const size_t K = h->p.K, Kp = h->p.Kp, T = h->p.T, n = K * T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
     BN_HIP(bn::launch_controls_to_reference(h->d_U + (size_t)instance * Kp * T * 2, h->d_scratch, (int)K, (int)Kp, (int)T,
@@ -1288,6 +1444,7 @@ int bn_mppi_get_philox_noise(bn_mppi_t *h, int32_t instance, uint64_t solve_inde
     if (int rc = check_instance(h, instance, false)) return rc;
     if (!out_host) return fail(BN_ERR_INVALID, "null output");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     const size_t n = (size_t)h->p.K * h->p.T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
     BN_HIP(bn::launch_philox_noise(h->d_scratch, h->p.seed, solve_index, instance, h->p.K, h->p.T, h->p.k0, h->stream));
@@ -1320,6 +1477,7 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
     if (n == 0) return BN_OK;
     if (!states_host || !weights_host) return fail(BN_ERR_INVALID, "null output");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     const size_t K = h->p.K, T1 = h->p.T + 1;
     std::vector<float> w(K);
     if (int rc = flush_tail(h)) return rc;
@@ -1369,6 +1527,7 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!(h->cfg.flags & BN_FLAG_PROFILE)) return fail(BN_ERR_STATE, "handle was created without BN_FLAG_PROFILE");
     BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
     if (h->pipelined || h->ticket_mode) {
         // close the open group with one more event *before* the flush, then average complete groups only
         const int open = h->prof_in_group;

@@ -363,12 +363,22 @@ __device__ __forceinline__ void st(float *ptr, float v) { if (AGENT) store_agent
 
 // Overlapped launches: a counter another launch advances (device-scope atomics) reaches `need`.  ONE lane polls, with sc1 loads
 // and s_sleep in between; the caller puts a workgroup barrier behind it.  Bounded: a wait that does not end within ~2 s sets
-// *err and gives up -- a wrong result that bn_mppi_sync reports, never a hung GPU.
+// *err and gives up -- a wrong result that the host sees at its next synchronising call (and repairs: recover_overlap in mppi_capi.cpp), never a hung GPU.
 // SLEEP: s_sleep argument between polls (x 64 cycles).  1 where the wait is short and on the critical path (latency kernel); the
 // role kernel's workgroups may hold a slot for many microseconds with hundreds of them polling at once -- at s_sleep 1 their
 // loads saturate the memory channel the counters live in and everything else that touches it (measured: 40 instances, 31 us
 // per launch instead of 21) -- so they poll every ~0.5 us, and the counters are kFlagStride apart (one channel each).
 __device__ __forceinline__ unsigned long long *flag_ctr(unsigned long long *base, int i) { return base + (size_t)i * kFlagStride; }
+
+// The error word lives in pinned host memory (SolveParams::err): a system-scope store, so that the host sees it without a copy.
+__device__ __forceinline__ void raise_wait_expired(int *err) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// First launch of the batches enqueued since the host last checked the error word: workgroup 0 of every instance keeps the mean
+// this solve samples around (ml, in LDS), so that the host can re-run those batches on one stream should a wait expire.
+__device__ __forceinline__ void snapshot_mean(const SolveParams &p, int b, const float *ml, int lane)
+{
+    for (int j = lane; j < 2 * p.T; j += 64) p.mean_snap[(size_t)b * 2 * p.T + j] = ml[j];
+}
 
 template <int SLEEP = 1>
 __device__ __forceinline__ void wait_counter(const unsigned long long *ctr, unsigned long long need, int *err)
@@ -377,7 +387,7 @@ __device__ __forceinline__ void wait_counter(const unsigned long long *ctr, unsi
         if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
         __builtin_amdgcn_s_sleep(SLEEP);
     }
-    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    raise_wait_expired(err);
 }
 
 // Publish: every wave has seen its own sc1 stores acknowledged (vmcnt 0), the workgroup meets, one lane counts it in.
@@ -655,7 +665,9 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 // a stable copy of the costs, and the batch-1 rollout X* of U*.  NT threads (320 as the aux workgroup, 1024 stand-alone for large K).
 // LDS: [ window | ustar 2T | X* 3(T+1) | scale nblk | red 32 | group rows ceil(nblk/16) x (2+2T) if nblk > 64 | sampled mode: draws, (mean, std) window ]
 // AGENT: the launch overlaps its predecessor (other stream): wait for the counters first, read what the predecessor wrote with
-// device-scope loads, write what the successor's tail reads (mean) with device-scope stores.
+// device-scope loads, and write EVERY output with device-scope (sc1, write-through) stores: the tails of consecutive solves run in
+// different kernels, possibly on different XCDs, and write the same addresses -- the tail counter orders the stores themselves, but
+// a plain store may sit dirty in its XCD's L2 until its kernel ends, and which kernel ends last is not ordered by anything.
 template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false, bool WIDE = false>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
@@ -698,8 +710,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         for (int j = tid; j < 2 * T; j += NT) {
             const float u = p.ustar_prev[(size_t)b * 2 * T + j];
             us[j] = u;
-            p.ustar[(size_t)b * 2 * T + j] = u;
-            if (p.out_copy) p.out_copy[(size_t)b * 2 * T + j] = u;
+            st<AGENT>(p.ustar + (size_t)b * 2 * T + j, u);
+            if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, u);
         }
         m = p.stats_prev[b * 2 + 0];
         S = p.stats_prev[b * 2 + 1];
@@ -707,15 +719,15 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     } else {
         merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
         for (int j = tid; j < 2 * T; j += NT) {
-            p.ustar[(size_t)b * 2 * T + j] = us[j];
-            if (p.out_copy) p.out_copy[(size_t)b * 2 * T + j] = us[j];
-            if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = ld<AGENT>(p.mean + (size_t)b * 2 * T + j);   // what this solve sampled around
+            st<AGENT>(p.ustar + (size_t)b * 2 * T + j, us[j]);
+            if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, us[j]);
+            if (p.mean_used) st<AGENT>(p.mean_used + (size_t)b * 2 * T + j, ld<AGENT>(p.mean + (size_t)b * 2 * T + j));   // what this solve sampled around
             st<AGENT>(p.mean + (size_t)b * 2 * T + j, us[j]);  // _previous_action_seq = U*, no shift (mppi.py:217)
         }
     }
     if (tid == 0) {
-        p.stats[b * 2 + 0] = m;
-        p.stats[b * 2 + 1] = S;
+        st<AGENT>(p.stats + b * 2 + 0, m);
+        st<AGENT>(p.stats + b * 2 + 1, S);
     }
     if (p.env_on && tid == 64) {
         // the environment step that follows this solve: apply U*[0], log state, reward and goal arrival
@@ -723,7 +735,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         const size_t B = p.B;
         float *row = p.ep_states + ((size_t)(p.ep_index + 1) * B + b) * 3;
         row[0] = e.x; row[1] = e.y; row[2] = e.th;
-        p.env_state[b * 3 + 0] = e.x; p.env_state[b * 3 + 1] = e.y; p.env_state[b * 3 + 2] = e.th;
+        st<AGENT>(p.env_state + b * 3 + 0, e.x); st<AGENT>(p.env_state + b * 3 + 1, e.y); st<AGENT>(p.env_state + b * 3 + 2, e.th);
         p.ep_reward[(size_t)p.ep_index * B + b] = e.reward;
         p.ep_action[((size_t)p.ep_index * B + b) * 2 + 0] = us[0];
         p.ep_action[((size_t)p.ep_index * B + b) * 2 + 1] = us[1];
@@ -839,8 +851,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         float *cout = p.cost_out + (size_t)b * K;
         for (int k = tid - 64; k < K; k += NT - 64) {
             const float ck = ld<AGENT>(cost + k);
-            cout[k] = ck;
-            wout[k] = expf((-ck) / p.lambda_ - m) / S;
+            st<AGENT>(cout + k, ck);
+            st<AGENT>(wout + k, expf((-ck) / p.lambda_ - m) / S);
         }
     }
     if constexpr (NT == 64) {                          // single-wave tail: the weights follow the X* rollout
@@ -860,8 +872,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         float *Xc = p.out_copy ? p.out_copy + (size_t)p.B * 2 * T + (size_t)b * (T + 1) * 3 : nullptr;
         for (int i = tid; i < 3 * (T + 1); i += NT) {
             const float v = xl[i];
-            Xg[i] = v;
-            if (Xc) Xc[i] = v;
+            st<AGENT>(Xg + i, v);
+            if (Xc) st<AGENT>(Xc + i, v);
         }
     }
     // one more tail done (counted per instance): what an overlapped successor's tail waits for before it takes the output buffers

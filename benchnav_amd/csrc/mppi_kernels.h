@@ -98,7 +98,9 @@ struct SolveParams {
     unsigned long long *flag_tail;       // [B] tails (aux workgroups / finish kernels) of instance b completed, ever
     unsigned long long wait_part;        // flag_part[prev_slot][b] value that means "the previous solve's partials and costs of this instance are all there"
     unsigned long long wait_tail;        // flag_tail[b] value that means "the tail before the one this launch carries is done"
-    int *err;                            // set non-zero when a bounded wait expired (reported by bn_mppi_sync)
+    int *err;                            // pinned host memory: set non-zero (system-scope store) when a bounded wait expired
+    float *mean_snap;                    // (B, T, 2) or nullptr: workgroup 0 of every instance keeps the mean this solve samples around
+                                         // (first launch since the host last checked `err`: where a re-run would start from)
     unsigned long long *gran, *gran_prev;   // (B, nblk, 2+2T) granule copies {value, tag} of this / the previous solve's partial rows
                                             // (overlapped batches with K <= 1024: the successor's prologue polls the rows themselves)
     float *w;            // (B, K)

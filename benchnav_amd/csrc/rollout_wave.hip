@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
         else { p.state_copy[b * 3 + 0] = sx; p.state_copy[b * 3 + 1] = sy; p.state_copy[b * 3 + 2] = sth; }
     }
     __syncthreads();
+    if (p.mean_snap && wg.blk == 0) snapshot_mean(p, b, ml, lane);
     const size_t Kp = (size_t)p.Kp;
     const bool lean = p.lean != 0;                    // lean mode: no trajectory batch (p.X is null)
     float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;

@@ -19,7 +19,7 @@ import torch.nn as nn
 import ctypes as C
 
 from . import _capi
-from .mppi import _DevArray, _planner_inputs
+from .mppi import MPPI as _MPPI, _DevArray, _planner_inputs
 from .native import NativeMPPI
 
 
@@ -51,11 +51,12 @@ class DWA(nn.Module):
         self._num_lin_vel, self._num_ang_vel = num_lin_vel, num_ang_vel
         inp = _planner_inputs(dynamics, objectives)
         self._goal = torch.as_tensor(inp["goal"]).detach().to("cpu", dtype)
+        self._stream = torch.cuda.current_stream(self._device)         # the library enqueues here; other current streams are fenced
         self._native = NativeMPPI(horizon=horizon, num_samples=64, grid_size=inp["grid_size"], resolution=inp["resolution"],
                                   x_limits=inp["x_limits"], y_limits=inp["y_limits"],
                                   u_min=self._u_min.tolist(), u_max=self._u_max.tolist(),
                                   stuck_threshold=inp["stuck_threshold"], device_id=self._device.index,
-                                  stream=torch.cuda.current_stream(self._device).cuda_stream)
+                                  stream=self._stream.cuda_stream)
         self._risk_cpu = inp["risks"].detach().to("cpu", torch.float32).contiguous()
         self._grid = (inp["grid_size"], inp["resolution"], inp["x_limits"], inp["y_limits"])
         self._native.set_map(self._risk_cpu.numpy())
@@ -125,23 +126,28 @@ class DWA(nn.Module):
         if state.device != self._device or state.dtype != self._dtype or not state.is_contiguous():
             state = state.detach().to(self._device, self._dtype).contiguous()
         prev = self._previous_action_seq
-        if prev is not self._prev_seen[0] or prev._version != self._prev_seen[1]:      # assigned or modified by the caller (or the
-            self._prev_buf.copy_(prev[:1].to(self._device, self._dtype))               # initial zeros): mirror its first row
-        n = self._num_lin_vel * self._num_ang_vel
         x_opt = torch.empty(1, self._horizon + 1, 3, device=self._device, dtype=self._dtype)
         path = self._path_dev
-        _capi.check(self._native._lib.bn_mppi_dwa_forward_async(
-            self._native._h, state.data_ptr(), self._prev_buf.data_ptr(), self._a_lim_c, self._delta_t, self._num_lin_vel,
-            self._num_ang_vel, None if path is None else path.data_ptr(), 0 if path is None else path.shape[0],
-            self._lookahead_distance, x_opt.data_ptr()))
+        # Called under another current stream than the one captured at construction: fence the two (as MPPI.forward does), so
+        # that the state / window-centre reads and the clone below are ordered with the kernels.
+        with _MPPI._Fence(self):
+            with torch.cuda.stream(self._stream):
+                if prev is not self._prev_seen[0] or prev._version != self._prev_seen[1]:      # assigned or modified by the caller (or the
+                    self._prev_buf.copy_(prev[:1].to(self._device, self._dtype))               # initial zeros): mirror its first row
+                _capi.check(self._native._lib.bn_mppi_dwa_forward_async(
+                    self._native._h, state.data_ptr(), self._prev_buf.data_ptr(), self._a_lim_c, self._delta_t, self._num_lin_vel,
+                    self._num_ang_vel, None if path is None else path.data_ptr(), 0 if path is None else path.shape[0],
+                    self._lookahead_distance, x_opt.data_ptr()))
+                optimal_action_seq = self._prev_buf.clone()             # (1,2): the argmin action, written by the kernel
         self._keep = state
-        optimal_action_seq = self._prev_buf.clone()                     # (1,2): the argmin action, written by the kernel
         self._previous_action_seq = optimal_action_seq                  # dwa.py:147
         self._prev_seen = (optimal_action_seq, optimal_action_seq._version)
         self._solved = True
         return optimal_action_seq, x_opt
 
     def _scratch_views(self):
+        """Views of the library's scratch block: valid until the next forward() (which overwrites, and may regrow, it).
+        Internal; the public attributes below hand out copies like the reference's fresh tensors (dwa.py:148-149)."""
         n = self._num_lin_vel * self._num_ang_vel
         xp, cp, wp = self._native.dwa_buffers(n)
         return (torch.as_tensor(_DevArray(xp, (n, self._horizon + 1, 3)), device=self._device),
@@ -149,31 +155,36 @@ class DWA(nn.Module):
 
     @property
     def _state_seq_batch(self) -> torch.Tensor:
-        """(n, T+1, 3) candidate trajectories of the latest forward(): a view of the library's buffer (next call overwrites it)."""
+        """(n, T+1, 3) candidate trajectories of the latest forward() (a copy: the library's buffer is reused by the next call)."""
         if not self._solved:
             return torch.zeros(self._num_lin_vel * self._num_ang_vel, self._horizon + 1, self._dim_state, device=self._device, dtype=self._dtype)
-        return self._scratch_views()[0]
+        with _MPPI._Fence(self), torch.cuda.stream(self._stream):
+            return self._scratch_views()[0].clone()
 
     @property
     def _costs(self) -> torch.Tensor:
-        return self._scratch_views()[1]
+        with _MPPI._Fence(self), torch.cuda.stream(self._stream):
+            return self._scratch_views()[1].clone()
 
     @property
     def _weights(self) -> torch.Tensor:
         if not self._solved:
             return torch.zeros(self._num_lin_vel * self._num_ang_vel, device=self._device, dtype=self._dtype)
-        return self._scratch_views()[2]
+        with _MPPI._Fence(self), torch.cuda.stream(self._stream):
+            return self._scratch_views()[2].clone()
 
     def last_candidates(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(actions (n,2), sub_goal (2,)) the latest forward() used, as computed on the device."""
         n = self._num_lin_vel * self._num_ang_vel
         a, g = C.c_void_p(), C.c_void_p()
         _capi.check(self._native._lib.bn_mppi_dwa_candidates(self._native._h, n, C.byref(a), C.byref(g)))
-        return (torch.as_tensor(_DevArray(a.value, (n, 2)), device=self._device).clone(),
-                torch.as_tensor(_DevArray(g.value, (2,)), device=self._device).clone())
+        with _MPPI._Fence(self), torch.cuda.stream(self._stream):
+            return (torch.as_tensor(_DevArray(a.value, (n, 2)), device=self._device).clone(),
+                    torch.as_tensor(_DevArray(g.value, (2,)), device=self._device).clone())
 
     def get_top_samples(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """All candidates sorted by weight, best first (dwa.py:287-299)."""
-        X, _, w = self._scratch_views()
-        order = torch.argsort(w, descending=True)
-        return X[order], w[order]
+        with _MPPI._Fence(self), torch.cuda.stream(self._stream):
+            X, _, w = self._scratch_views()
+            order = torch.argsort(w, descending=True)
+            return X[order], w[order]

@@ -26,7 +26,31 @@ import torch
 from . import _capi
 
 
+def env_inputs(env) -> dict:
+    """What a BatchedPlanetaryEnv needs, read off a reference-shaped `PlanetaryEnv` (planetary_env.py:58-92): the latent slip
+    model its observation-mode dynamics sample from (`grid_map.distributions["latent_models"]`, traversability_model.py:65-69),
+    start / goal, time step and limit, the two thresholds, the seed, and the grid geometry.  Pinned against the real class by
+    tests/golden/boundary.json (attribute names) and boundary.npz (values)."""
+    gm = env._grid_map
+    latent = gm.distributions["latent_models"]
+    return dict(latent_mean=latent.mean, latent_std=latent.stddev, start_pos=env._start_pos, goal_pos=env._goal_pos,
+                delta_t=float(env._delta_t), time_limit=float(env._time_limit), stuck_threshold=float(env.stuck_threshold),
+                goal_threshold=float(env._goal_threshold), seed=env._seed, grid_size=int(gm.grid_size), resolution=float(gm.resolution),
+                x_limits=(float(gm.x_limits[0]), float(gm.x_limits[1])), y_limits=(float(gm.y_limits[0]), float(gm.y_limits[1])))
+
+
 class BatchedPlanetaryEnv:
+    @classmethod
+    def from_reference(cls, planner, env, freeze_on_goal: bool = False) -> "BatchedPlanetaryEnv":
+        """B device-side copies of one reference `PlanetaryEnv` (same map, start, goal, thresholds), for a planner with B instances."""
+        inp = env_inputs(env)
+        if inp["grid_size"] != planner.G:
+            raise ValueError(f"the environment's grid ({inp['grid_size']}) is not the planner's ({planner.G})")
+        f32 = lambda t: t.detach().to("cpu", torch.float32).numpy()
+        return cls(planner, f32(inp["latent_mean"]), f32(inp["latent_std"]), f32(inp["start_pos"]), f32(inp["goal_pos"]),
+                   delta_t=inp["delta_t"], time_limit=inp["time_limit"], stuck_threshold=inp["stuck_threshold"],
+                   goal_threshold=inp["goal_threshold"], seed=inp["seed"], freeze_on_goal=freeze_on_goal)
+
     def __init__(self, planner, latent_mean, latent_std, start_pos, goal_pos, delta_t: float = 0.1, time_limit: float = 100.0,
                  stuck_threshold: float = 0.1, goal_threshold: float = 1.0, seed: Optional[int] = None, freeze_on_goal: bool = False):
         """planner: NativeMPPI with B instances (its goals are set from goal_pos), created on torch's current stream of its

@@ -39,6 +39,21 @@ class _DevArray:
         }
 
 
+# Every private attribute of the reference's objects the native planners read, by reference class.  The golden
+# fixture tests/golden/boundary.json records the attributes the REAL classes carry (tests/golden/make_golden.py imports them);
+# tests/test_boundary_golden.py checks this table against it, and rebuilds reference-shaped objects from nothing but the recorded
+# names to run _planner_inputs / env_inputs on them.
+REFERENCE_READS = {
+    "UnicycleModel": ["_grid_map", "_model_config", "_traversability_model", "min_action", "max_action"],   # robot_model.py:33-44
+    "ModelConfig": ["mode"],                                                                                  # utils.py:10-14
+    "TraversabilityModel": ["_risks"],                                                                        # traversability_model.py:24-26
+    "GridMap": ["grid_size", "resolution", "x_limits", "y_limits", "distributions"],                          # grid_map.py:40-58
+    "Objectives": ["_goal_pos", "_stuck_threshold"],                                                          # objectives.py:26-27
+    "PlanetaryEnv": ["_grid_map", "_start_pos", "_goal_pos", "_delta_t", "_time_limit", "stuck_threshold",    # planetary_env.py:58-92
+                     "_goal_threshold", "_seed"],
+}
+
+
 def _planner_inputs(dynamics, objectives, sampled_slip=False):
     """What the native planner reads from the reference-shaped `dynamics` / `objectives`
     objects: the risk map, the grid geometry, the action bounds, the goal

@@ -238,6 +238,10 @@ class NativeMPPI:
         """Write the pending tail of the latest solve and wait for the stream."""
         _capi.check(self._lib.bn_mppi_sync(self._h))
 
+    def recovery_count(self) -> int:
+        """How many times batches were re-run after an expired device-side wait of an overlapped launch (0 normally)."""
+        return int(self._lib.bn_mppi_recovery_count(self._h))
+
     def flush(self):
         """Enqueue the pending tail (U*, X*, weights of the latest solve) without waiting."""
         _capi.check(self._lib.bn_mppi_flush(self._h))

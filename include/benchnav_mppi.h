@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BN_MPPI_ABI_VERSION 1
+#define BN_MPPI_ABI_VERSION 2
 
 typedef enum bn_status {
     BN_OK = 0,
@@ -182,7 +182,15 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
  * internal one and overlap: solve i+1 is dispatched while solve i runs and waits on a device counter for its
  * partials instead of for its kernel's end; the call forks from and joins back into the handle's stream, so the
  * caller sees ordinary stream order, and the results are bit-identical (BN_FLAG_NO_OVERLAP turns it off).
- * Device-side waits are bounded; bn_mppi_sync reports BN_ERR_HIP if one expired. */
+ * Device-side waits are bounded (~2 s: another user of the GPU kept a predecessor from becoming resident).  If one expires the
+ * launch computes on incomplete partials; the error word it sets lives in pinned host memory and is looked at by EVERY entry
+ * point that synchronises (bn_mppi_sync, the getters, the setters, bn_mppi_episode_log ...) and by bn_mppi_flush: the batches
+ * enqueued since the last clean synchronisation point are then RE-RUN on one stream from the mean the first of them started
+ * from (kept on the device), with the same Philox positions and the callers' state / noise buffers -- which therefore must stay
+ * valid and unchanged until the synchronisation point that follows a batch.  The call returns BN_OK with a warning in
+ * bn_last_error(), bn_mppi_recovery_count() counts these events (consumers enqueued in stream order BEFORE the
+ * synchronisation point have read invalid buffers), and the handle keeps to one stream from then on.  BN_ERR_HIP only when the
+ * batches cannot be re-run (host-resident inputs, more than 4096 batches without a synchronising call). */
 int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
 
@@ -264,12 +272,16 @@ int bn_mppi_dwa_forward_async(bn_mppi_t *h, const float *states_device, float *p
                               float dwa_delta_t, int32_t num_lin_vel, int32_t num_ang_vel, const float *path_device, int32_t num_path,
                               float lookahead, float *best_states_device);
 int bn_mppi_dwa_candidates(bn_mppi_t *h, int32_t num_actions, const float **actions_device, const float **stage_goal_device);
+/* Write the pending tail, wait for the handle's stream, check the overlapped launches' error word (see bn_mppi_solve_n_async). */
 int bn_mppi_sync(bn_mppi_t *h);
-/* Test hook: mark the latest overlapped batch as if one of its bounded device-side waits had expired (what happens when another
- * process keeps a launch's predecessor from becoming resident for ~2 s).  The next bn_mppi_sync reports BN_ERR_HIP, resets the
- * launch counters and keeps the handle on one stream from then on. */
+/* How many times this handle re-ran batches after an expired device-side wait (0 in normal operation). */
+uint64_t bn_mppi_recovery_count(const bn_mppi_t *h);
+/* Test hook: behave as if a bounded device-side wait had expired in the batches enqueued since the last synchronisation point
+ * (what happens when another process keeps a launch's predecessor from becoming resident for ~2 s): sets the error word and
+ * overwrites what those batches wrote (mean, U* | X*, weights, costs, trajectories) with NaN patterns.  The next synchronising
+ * call re-runs them on one stream. */
 int bn_mppi_debug_expire_wait(bn_mppi_t *h);
-/* Enqueue the pending tail (if any) without waiting. */
+/* Enqueue the pending tail (if any) without waiting.  An expiry that has already been flagged is repaired here (that does wait). */
 int bn_mppi_flush(bn_mppi_t *h);
 
 /* Copies of the planner state in the REFERENCE's layouts (host arrays).  All

@@ -501,8 +501,90 @@ def run_instance_io_case():
     print(f"instance       G={G}: written by benchnav_amd.io, read by the reference's GridMap -> {os.path.getsize(p_)/1024:.0f} KiB + {os.path.getsize(path)/1024:.0f} KiB .pt")
 
 
+def _attrs_of(obj):
+    """Attribute name -> a short description of what the REAL object holds there (no values beyond scalars)."""
+    out = {}
+    for k, v in vars(obj).items():
+        if torch.is_tensor(v):
+            out[k] = f"tensor{list(v.shape)}:{str(v.dtype).replace('torch.', '')}"
+        elif isinstance(v, (bool, int, float, str, type(None))):
+            out[k] = f"{type(v).__name__}:{v!r}"
+        elif isinstance(v, (tuple, list)):
+            out[k] = f"{type(v).__name__}[{len(v)}]"
+        elif isinstance(v, dict):
+            out[k] = "dict:" + ",".join(sorted(map(str, v.keys())))
+        else:
+            out[k] = type(v).__name__
+    return out
+
+
+def run_boundary_case():
+    """A11: the duck-typed boundary pinned against the REAL classes.  benchnav_amd's extractors (_planner_inputs for MPPI / DWA,
+    env_inputs for the batched environment) are called on the reference's own UnicycleModel / Objectives / GridMap /
+    PlanetaryEnv; what they return goes to boundary.npz, the attributes the real objects carry to boundary.json.  The CPU test
+    rebuilds reference-shaped objects from the recorded NAMES alone and must get the same answers -- a rename on either side
+    breaks it (here at regeneration, there in the test)."""
+    import json
+    from src.simulator.planetary_env import PlanetaryEnv
+    from benchnav_amd.mppi import _planner_inputs, REFERENCE_READS
+    from benchnav_amd.env import env_inputs
+    G, res, thr = 48, 0.25, 0.35
+    mean_map, std_map = smooth_risk_map(G, 41) * 0.7, slip_std_map(G, 41)
+    goal = torch.tensor([9, 8])                                       # int64, as test_mppi.py:133 passes it
+    torch.manual_seed(4321)
+    gm, dyn, obj = build_reference(G, res, mean_map, std_map, "cvar", 0.9, goal, thr)      # test_mppi.py:146-157
+    gm_o = _env_grid_map(G, res, mean_map, std_map)
+    dyn_obs = UnicycleModel(gm_o, ModelConfig(mode="observation"), device="cpu")
+    obj_obs = Objectives(dyn_obs, goal_pos=goal, stuck_threshold=thr)
+    a = _planner_inputs(dyn, obj)
+    b = _planner_inputs(dyn_obs, obj_obs, sampled_slip=True)
+    raised = {}
+    for key, args in (("observation_without_sampled_slip", (dyn_obs, obj_obs, False)), ("inference_with_sampled_slip", (dyn, obj, True))):
+        try:
+            _planner_inputs(*args)
+            raised[key] = None
+        except Exception as e:                                        # noqa: BLE001 - the type is what is recorded
+            raised[key] = type(e).__name__
+    # the reference's own MPPI on observation-mode dynamics: what the drop-in class must mimic (SURVEY 0.9)
+    try:
+        MPPI(horizon=5, num_samples=8, dim_state=3, dim_control=2, dynamics=dyn_obs, objectives=obj_obs, sigmas=torch.tensor([0.5, 0.5]),
+             lambda_=0.5, device=torch.device("cpu"))(torch.tensor([3.0, 3.0, 0.0]))
+        raised["reference_mppi_on_observation_mode"] = None
+    except Exception as e:                                            # noqa: BLE001
+        raised["reference_mppi_on_observation_mode"] = type(e).__name__
+    env = PlanetaryEnv(grid_map=gm_o, start_pos=torch.tensor([2.0, 2.5]), goal_pos=torch.tensor([9.0, 8.0]), seed=7, delta_t=0.1,
+                       time_limit=37.0, stuck_threshold=0.05, goal_threshold=0.8, device="cpu")
+    e = env_inputs(env)
+    names = {"UnicycleModel": _attrs_of(dyn), "UnicycleModel(observation)": _attrs_of(dyn_obs), "ModelConfig": _attrs_of(dyn._model_config),
+             "TraversabilityModel": _attrs_of(dyn._traversability_model), "GridMap": _attrs_of(gm), "Objectives": _attrs_of(obj),
+             "PlanetaryEnv": _attrs_of(env)}
+    for cls_, reads in REFERENCE_READS.items():
+        missing = [r for r in reads if r not in names[cls_]]
+        assert not missing, f"benchnav_amd reads {missing} from {cls_}, which the reference class does not carry"
+    meta = dict(torch_version=torch.__version__, attributes=names, raised=raised,
+                latent_distribution=type(gm.distributions["latent_models"]).__name__, distributions=sorted(gm.distributions.keys()))
+    with open(os.path.join(HERE, "boundary.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    f32 = lambda t: np.asarray(torch.as_tensor(t).detach().cpu().numpy())
+    out = dict(G=G, res=res, thr=thr, MU=mean_map.numpy(), SG=std_map.numpy(),
+               inf_risks=f32(a["risks"]), inf_goal=f32(a["goal"]), inf_scalars=np.array([a["grid_size"], a["resolution"], *a["x_limits"], *a["y_limits"], a["stuck_threshold"]], np.float64),
+               obs_risks=f32(b["risks"]), obs_slip_std=f32(b["slip_std"]), obs_goal=f32(b["goal"]),
+               obs_scalars=np.array([b["grid_size"], b["resolution"], *b["x_limits"], *b["y_limits"], b["stuck_threshold"]], np.float64),
+               u_min=f32(dyn.min_action), u_max=f32(dyn.max_action),
+               env_latent_mean=f32(e["latent_mean"]), env_latent_std=f32(e["latent_std"]), env_start=f32(e["start_pos"]), env_goal=f32(e["goal_pos"]),
+               env_scalars=np.array([e["delta_t"], e["time_limit"], e["stuck_threshold"], e["goal_threshold"], e["seed"], e["grid_size"], e["resolution"],
+                                     *e["x_limits"], *e["y_limits"]], np.float64),
+               env_robot_state0=f32(env._robot_state))
+    p_ = os.path.join(HERE, "boundary.npz")
+    np.savez_compressed(p_, **out)
+    print(f"boundary       real UnicycleModel / Objectives / GridMap / PlanetaryEnv through _planner_inputs / env_inputs; raised={raised} -> "
+          f"{os.path.getsize(p_)/1024:.0f} KiB + boundary.json")
+
+
 def main():
     pi = math.pi
+    if sys.argv[1:] == ["boundary"]:
+        return run_boundary_case()
     if sys.argv[1:] == ["instance"]:
         return run_instance_io_case()
     if sys.argv[1:] == ["sampled"]:
@@ -513,6 +595,7 @@ def main():
         return run_env_case()
     if sys.argv[1:] == ["episodes"]:
         return run_episode_case()
+    run_boundary_case()
     run_env_case()
     run_episode_case()
     run_instance_io_case()

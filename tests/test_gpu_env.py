@@ -222,3 +222,38 @@ def test_a_private_planner_stream_is_refused():
         pl.set_map(mu)
         with pytest.raises(RuntimeError, match="current stream"):
             BatchedPlanetaryEnv(pl, mu, sg, [4.0, 4.0], [10.0, 10.0])
+
+
+def test_from_reference_shaped_environment():
+    """BatchedPlanetaryEnv.from_reference on an object carrying exactly the attributes the REAL PlanetaryEnv had when
+    tests/golden/make_golden.py ran (boundary.json) and the values it held (boundary.npz): same start state as the real
+    environment's, thresholds and time step taken over."""
+    import json
+    import os
+    import types
+    import torch
+    from benchnav_amd import NativeMPPI
+    from benchnav_amd.env import BatchedPlanetaryEnv
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(here, "boundary.json")))
+    fx = np.load(os.path.join(here, "boundary.npz"))
+    sc = fx["env_scalars"]
+    G, res = int(sc[5]), float(sc[6])
+    latent = torch.distributions.Normal(torch.as_tensor(fx["MU"]), torch.as_tensor(fx["SG"]))
+    gm = types.SimpleNamespace(**{k: None for k in meta["attributes"]["GridMap"]})
+    gm.grid_size, gm.resolution, gm.x_limits, gm.y_limits = G, res, (float(sc[7]), float(sc[8])), (float(sc[9]), float(sc[10]))
+    gm.distributions = {"latent_models": latent}
+    env_ref = types.SimpleNamespace(**{k: None for k in meta["attributes"]["PlanetaryEnv"]})
+    env_ref._grid_map, env_ref._start_pos, env_ref._goal_pos = gm, torch.as_tensor(fx["env_start"]), torch.as_tensor(fx["env_goal"])
+    env_ref._delta_t, env_ref._time_limit, env_ref.stuck_threshold, env_ref._goal_threshold, env_ref._seed = (float(sc[0]), float(sc[1]), float(sc[2]),
+                                                                                                           float(sc[3]), int(sc[4]))
+    B = 3
+    with NativeMPPI(horizon=10, num_samples=64, grid_size=G, resolution=res, num_instances=B, shared_map=True, stream=0) as pl:
+        pl.set_map(fx["MU"])
+        env = BatchedPlanetaryEnv.from_reference(pl, env_ref)
+        s0 = env.reset()
+        assert s0.shape == (B, 3)
+        assert np.allclose(s0.cpu().numpy(), np.broadcast_to(fx["env_robot_state0"], (B, 3)), atol=1e-6)
+        assert env._delta_t == float(sc[0]) and env._time_limit == float(sc[1]) and env.stuck_threshold == float(sc[2]) and env._goal_threshold == float(sc[3])
+        ns, reward, term, trunc = env.step(torch.tensor([[0.5, 0.1]] * B, device="cuda"))
+        assert ns.shape == (B, 3) and bool(torch.isfinite(ns).all()) and trunc is False

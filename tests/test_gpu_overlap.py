@@ -165,11 +165,13 @@ def test_big_batches_behind_pending_work_do_not_crowd_each_other_out():
             assert np.array_equal(a_, c_), j
 
 
-def test_an_expired_wait_is_reported_once_and_leaves_a_working_one_stream_handle():
-    """A bounded device-side wait that expires (another process keeping a predecessor off the chip) makes sync() raise; the
-    handle then resets its launch counters, drops the pending tail and keeps to one stream.  With the test hook: after the
-    error and a fresh warm start the handle computes what a handle that never overlapped computes (injected noise, so the
-    number of solves that went before does not matter)."""
+def test_an_expired_wait_is_repaired_by_a_rerun_on_one_stream():
+    """A bounded device-side wait that expires (another process keeping a predecessor off the chip) spoils the batches enqueued
+    since the last synchronisation point.  Every synchronising entry point -- a getter here, not only sync() -- notices the error
+    word and re-runs those batches on one stream from the mean the first of them started from.  With the test hook (which also
+    overwrites everything the batches wrote with NaN patterns): two chained batches behind a warm-up, then weights / costs / mean /
+    trajectories equal to a handle that never overlapped; the event is counted, warned about once, and the handle keeps to one
+    stream (and keeps working) afterwards."""
     import torch
     from benchnav_amd import _capi, synth
     K, T, B, n = 1024, 50, 2, 6
@@ -178,22 +180,51 @@ def test_an_expired_wait_is_reported_once_and_leaves_a_working_one_stream_handle
     eps = np.random.default_rng(12).standard_normal((n, B, K, T, 2)).astype(np.float32)
     ed = torch.from_numpy(eps).cuda()
     torch.cuda.synchronize()
-    run = lambda pl: pl.solve_n_async_device(n, st.data_ptr(), ed.data_ptr(), _capi.BN_NOISE_DEVICE_KT2, n, eps[0].size)
+    run = lambda pl, m=n: pl.solve_n_async_device(m, st.data_ptr(), ed.data_ptr(), _capi.BN_NOISE_DEVICE_KT2, n, eps[0].size)
     with _make(K, T, B, insts, False) as ref:
-        run(ref)
+        run(ref); run(ref, 4); run(ref, 5)
         want = _outputs(ref, B, T)
+        run(ref, 3)
+        want2 = _outputs(ref, B, T)
     with _make(K, T, B, insts, True) as pl:
-        run(pl)
+        run(pl)                                              # a batch that is checked clean ...
+        pl.sync()
+        assert pl.recovery_count() == 0
+        run(pl, 4); run(pl, 5)                               # ... and two, chained, that are not
         _capi.check(pl._lib.bn_mppi_debug_expire_wait(pl._h))
-        with pytest.raises(_capi.BenchnavError, match="gave up waiting"):
-            pl.sync()
-        pl.sync()                                            # reported once
-        pl.set_mean()                                        # fresh warm start (zeros), every instance
-        run(pl)                                              # one stream now
+        w0 = pl.weights(0)                                   # a getter, not sync(): repaired here
+        assert np.isfinite(w0).all()
+        assert pl.recovery_count() == 1
+        assert b"re-run on one stream" in pl._lib.bn_last_error()
         got = _outputs(pl, B, T)
-    for b in range(B):
-        for j, (a_, c_) in enumerate(zip(got[b], want[b])):
-            assert np.array_equal(a_, c_), (b, j)
+        assert pl.recovery_count() == 1                      # repaired once
+        run(pl, 3)                                           # one stream now; the chain goes on from the repaired mean
+        got2 = _outputs(pl, B, T)
+        assert pl.recovery_count() == 1
+    for g_, w_ in ((got, want), (got2, want2)):
+        for b in range(B):
+            for j, (a_, c_) in enumerate(zip(g_[b], w_[b])):
+                assert np.array_equal(a_, c_), (b, j)
+
+
+def test_an_expired_wait_in_an_episode_is_repaired():
+    """The device-side closed loop is journalled as a whole: after the hook the log read-back equals the one-stream episode's."""
+    from benchnav_amd import _capi, synth
+    K, T, B, steps = 512, 20, 2, 12
+    insts = [synth.make_instance(G, seed=70 + b) for b in range(B)]
+    logs = {}
+    for overlap in (False, True):
+        with _make(K, T, B, insts, overlap) as pl:
+            pl.env_attach(np.stack([it.risk.numpy() for it in insts]), np.full((B, G, G), 0.05, np.float32))
+            st0 = np.stack([it.start.numpy() for it in insts])
+            pl.episode(steps, st0, wait=False)
+            if overlap:
+                _capi.check(pl._lib.bn_mppi_debug_expire_wait(pl._h))
+            logs[overlap] = pl.episode_log()
+            if overlap:
+                assert pl.recovery_count() == 1
+    for a_, c_ in zip(logs[True], logs[False]):
+        assert np.array_equal(a_, c_)
 
 
 def test_two_handles_in_flight_do_not_starve_each_other():
