@@ -51,6 +51,31 @@ __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
     cs = __uint_as_float(__float_as_uint(C) ^ sign);
 }
 
+// ---- carried heading ---------------------------------------------------------
+// Within a rollout the heading vector (cos, sin) is set once from the start heading (sincos_spec) and then carried by a
+// rotation per step, (cs, sn) <- R(d)(cs, sn) with d the step's heading increment (robot_model.py:88), instead of being
+// re-evaluated from theta: 7 instructions (two of them scalar, five packed) where wrap + sincos take 21, on the one wave
+// whose issue slots are a solve's latency -- and theta itself drops out of the chain (it is an output only; whoever stores
+// the trajectory integrates and wraps it).  cos d and sin d / d are degree-6 Taylor polynomials in d (truncation d^8/40320:
+// 3e-13 at the reference's |d| <= 0.1, 1e-7 at 0.5, which is where bn_mppi_create draws the line); the rounding of a
+// step is carried along, ~sqrt(T) * 4e-8 after T steps.  DESIGN.md "Arithmetic spec"; restated independently by the
+// test oracle (bn_rotate_spec).  Scalar statement of what the packed stream computes:
+//   d2 = d*d; cd = fma(d2, fma(d2, fma(d2, C6, C4), C2), 1); sp = fma(d2, fma(d2, fma(d2, S7, S5), S3), 1); sd = d*sp;
+//   cs' = fma(cs, cd, -(sn*sd)); sn' = fma(sn, cd, cs*sd)
+__device__ __forceinline__ void rotate_spec(float &cs, float &sn, float d)
+{
+    const float d2 = d * d;
+    const v2f dd = {d2, d2};
+    v2f pq = __builtin_elementwise_fma(dd, v2f{-0.00138888892251998186f, -0.000198412701138295233f}, v2f{0.0416666679084300995f, 0.00833333376795053482f});
+    pq = __builtin_elementwise_fma(dd, pq, v2f{-0.5f, -0.16666667163372040f});
+    pq = __builtin_elementwise_fma(dd, pq, v2f{1.0f, 1.0f});                  // (cos d, sin d / d)
+    const float sd = d * pq.y;
+    const v2f t = v2f{-sn, cs} * v2f{sd, sd};                                  // (-(sn*sd), cs*sd): the negation is exact
+    const v2f r = __builtin_elementwise_fma(v2f{cs, sn}, v2f{pq.x, pq.x}, t);
+    cs = r.x;
+    sn = r.y;
+}
+
 // torch.remainder(a, b), b > 0: fmod (exact) then the divisor-sign fix.  The
 // fast paths return exactly what fmodf would (Sterbenz / identity).
 __device__ __forceinline__ float py_mod_pos(float a, float b)

@@ -358,6 +358,11 @@ int settle_overlap(bn_mppi *h, bool synced)
 int sync_checked(bn_mppi *h)
 {
     BN_HIP(hipStreamSynchronize(h->stream));
+    // the extra streams of an overlapped batch are not joined into the handle's stream (see bn_mppi_solve_n_async): their last
+    // kernels have done all their work by now -- the handle's stream consumed it -- and end within microseconds
+    if (h->overlap_used)
+        for (int q = 0; q + 1 < h->n_streams; ++q)
+            if (h->xstream[q]) BN_HIP(hipStreamSynchronize(h->xstream[q]));
     return settle_overlap(h, true);
 }
 
@@ -412,10 +417,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     for (int d = 0; d < 2; ++d)
         if (!(cfg->u_min[d] <= cfg->u_max[d]) || !(cfg->sigma[d] >= 0.0f))
             return fail(BN_ERR_INVALID, "need u_min <= u_max and sigma >= 0");
-    // After the first step the heading wrap runs in its branch-free near form (bn_device_math.h),
-    // valid while one step turns by less than pi.
-    if (!((double)cfg->dt * std::max(std::fabs((double)cfg->u_min[1]), std::fabs((double)cfg->u_max[1])) < 3.0))
-        return fail(BN_ERR_INVALID, "dt * max|omega| must stay below 3 rad per step");
+    // The heading vector is carried by a small-angle rotation per step (rotate_spec, bn_device_math.h): its degree-6 polynomials
+    // are good to 1e-7 up to 0.5 rad per step (the reference's dt = 0.1, |omega| <= 1 give 0.1); the branch-free near form of the
+    // heading wrap after the first step needs less than pi as well.
+    if (!((double)cfg->dt * std::max(std::fabs((double)cfg->u_min[1]), std::fabs((double)cfg->u_max[1])) <= 0.5))
+        return fail(BN_ERR_INVALID, "dt * max|omega| must not exceed 0.5 rad per step");
     // The kernels share one gather between stage cost t and transit t+1; that needs the upper clamp
     // to land in the last cell, as it does for every reference GridMap (grid_map.py:42-50).
     const float span_x = (cfg->x_limits[1] - cfg->x_limits[0]) / cfg->resolution;
@@ -735,7 +741,7 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
 
 // shard_rollout: the rollouts of a K-sharded solve only (bn_mppi_shard_rollout_async); the tail follows the exchange.
 static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise,
-                      bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr, int alt_buffers = 0)
+                      bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr, int alt_buffers = 0, bool self_tail = false)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!states) return fail(BN_ERR_INVALID, "states is null");
@@ -852,6 +858,12 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             if (p.overlap) { st = on_stream; h->overlap_used = true; }
             h->pub[cur3] += (unsigned long long)p.nblk;
             h->prev_published = true;
+            if (self_tail && p.lat_kernel && !h->in_episode) {         // last solve of a batch: its own tail rides in the same launch
+                p.self_tail = 1;
+                p.wait_part_self = h->pub[cur3];
+                p.wait_tail_self = h->tails;
+                h->tails += 1;
+            }
         } else {
             h->prev_published = false;
         }
@@ -861,7 +873,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         BN_HIP(bn::launch_rollout(p, mode, st));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
-        h->tail_pending = true;
+        h->tail_pending = !p.self_tail;
+        if (p.self_tail) h->prev_published = false;                // the next solve starts from the mean that tail writes, in stream order
         return BN_OK;
     }
     h->prev_published = false;
@@ -1050,6 +1063,9 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         BN_HIP(hipEventRecord(h->ev_fork, h->stream));              // (nothing is: no event packet in front of the first launches)
         for (int q = 0; q + 1 < S; ++q) BN_HIP(hipStreamWaitEvent(h->xstream[q], h->ev_fork, 0));
     }
+    static const bool exp_self_tail = std::getenv("BN_NO_SELF_TAIL") == nullptr;   // experiments (tools/region_overhead.py)
+    static const bool exp_align = std::getenv("BN_NO_ALIGN") == nullptr;
+    if (!exp_align) idle = false;                                   // (only the stream assignment below looks at it from here on)
     int rc = BN_OK;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
@@ -1058,14 +1074,18 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         // cross-queue event that has only just fired (measured: 18 us between the last rollout kernel and the tail).  With an
         // even n the last two solves share the stream, which costs one overlap.  (Not the first two: the solve on the other
         // stream would then become eligible before its predecessor is even dispatched -- see the note on eligibility above.)
-        const int q = i == n - 1 ? 0 : i % S;
-        rc = solve_impl(h, states, states_where, e, noise, false, true, q ? h->xstream[q - 1] : h->stream, q);
+        // On an idle stream nothing ties the first solve to the handle's stream, so the round robin is simply aligned to END there.
+        const int q = idle ? (n - 1 - i) % S : (i == n - 1 ? 0 : i % S);
+        // A long batch ends with its own tail (see below): on the latency kernel it rides in the last launch as a second aux workgroup.
+        const bool own_tail = i == n - 1 && n >= kEagerTailMinBatch && exp_self_tail;
+        rc = solve_impl(h, states, states_where, e, noise, false, true, q ? h->xstream[q - 1] : h->stream, q, own_tail);
     }
     // A long batch ends with its own tail, enqueued right behind the last solve and BEFORE the join: a tail kernel that comes later
     // (flush, sync, a getter) would sit behind the join's barrier packet, ~10 us of queue processing after the last rollout kernel.
     // Short batches keep the tail pending: chained short batches carry it in their next launch for free.
     if (rc == BN_OK && n >= kEagerTailMinBatch && !h->in_episode) rc = flush_tail(h);
-    for (int q = 0; q + 1 < S; ++q) {                               // join: the handle's stream continues behind all of them
+    static const bool exp_join = std::getenv("BN_JOIN") != nullptr;   // experiments (tools/region_overhead.py)
+    for (int q = 0; exp_join && q + 1 < S; ++q) {                   // join: the handle's stream continues behind all of them
         hipError_t e1 = hipEventRecord(h->ev_join[q], h->xstream[q]);
         hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join[q], 0);
         if (rc == BN_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(BN_ERR_HIP, "joining the overlapped launches failed");

@@ -74,16 +74,21 @@ struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; };   // window origin (cel
 // Which workgroup of which instance this is (see rollout_grid): rollout workgroup `blk` of instance `b`, or the aux
 // workgroup of instance `b` (tail of the previous solve).  Rows past the instances hold the aux workgroups, so they are
 // dispatched last; with xs = 3 the workgroups of one instance share an XCD (and its L2: window rows, partials).
-struct WgId { int b, blk; bool aux, idle; };
+struct WgId { int b, blk; bool aux, idle, self; };   // self: the aux workgroup that writes the tail of THIS launch's solve (SolveParams::self_tail)
 
 __device__ __forceinline__ WgId decode_wg(const SolveParams &p)
 {
     const int rows = (p.B + (1 << p.xs) - 1) >> p.xs;
     WgId r;
+    r.self = false;
     if ((int)blockIdx.y >= rows) {
         r.aux = true;
         r.blk = p.nblk;
         r.b = ((int)blockIdx.y - rows) * (int)gridDim.x + (int)blockIdx.x;
+        if (p.self_tail && r.b >= (p.have_prev ? p.B : 0)) {            // behind the previous solve's tails: this solve's own
+            r.self = true;
+            r.b -= p.have_prev ? p.B : 0;
+        }
     } else {
         r.aux = false;
         r.blk = (int)blockIdx.x >> p.xs;
@@ -179,17 +184,28 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
 // Per-rollout recurrence state: the clamped/wrapped state t, its traversability, sin/cos of its heading.
 struct Chain { float x, y, th, sn, cs, trav; };
 
+// The heading of a rollout as an OUTPUT: theta_{t+1} = wrap(theta_t + d_t) (robot_model.py:88,90), tn = the un-wrapped sum slot t
+// keeps.  The first step takes the general wrap (a caller's start heading may be anything), later ones the near form.
+__device__ __forceinline__ float theta_step(float &th, float dth, bool first)
+{
+    const float tn = th + dth;                                         // :88
+    th = first ? wrap_angle(tn) : wrap_angle_near(tn);                 // :90
+    return tn;
+}
+
 // One UnicycleModel.transit (robot_model.py:59-100) plus the gather for the next step.
 // (xn, yn, tn) is what the reference leaves in slot t (un-clamped, un-wrapped); the chain
-// advances to the clamped/wrapped state t+1.  The two dependent strands -- heading (wrap, sincos) and
-// position (clamp, cell index, LDS gather) -- are independent after `trav` and overlap in issue.
+// advances to the clamped/wrapped state t+1.  The heading enters the positions only through (cos, sin), which are CARRIED by a
+// rotation (rotate_spec); theta is integrated beside it when THETA is set (kernels whose one wave does everything).  With
+// THETA = false (the role kernels' chain wave) tn returns the step's heading increment d_t instead and c.th is not touched:
+// the wave that stores the trajectory integrates theta from the increments (theta_step).
 // u0, u1 already lie in [u_min, u_max]: the re-clamp of robot_model.py:82-83 is the identity.
-template <int GEO, bool LDSWIN, bool FIRST>
+template <int GEO, bool LDSWIN, bool FIRST, bool THETA = true>
 __device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
                                            const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn)
 {
-    // Position strand first: update, clamp, cell index, and the gather goes out; the heading strand (wrap, sin/cos,
-    // ~27 instructions) then runs under the gather's LDS latency.  The scheduling barrier keeps the compiler from
+    // Position strand first: update, clamp, cell index, and the gather goes out; the heading strand (rotation, 7
+    // instructions) then runs under the gather's LDS latency.  The scheduling barrier keeps the compiler from
     // interleaving the two again (it used to issue the gather two thirds into the step).
     const float tv = c.trav * u0;
     const float dth = (c.trav * u1) * p.dt;
@@ -202,11 +218,9 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     if (BN_ABLATE & 32) { c.trav = 0.5f + 0.001f * c.x; } else
     c.trav = LDSWIN ? trav_window<GEO>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
     __builtin_amdgcn_sched_barrier(0);
-    tn = c.th + dth;                                                   // :88
-    if (BN_ABLATE & 64) c.th = tn; else
-    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);               // :90
-    if (BN_ABLATE & 16) { c.sn = c.th * 0.5f; c.cs = 1.0f - c.th; } else
-    sincos_spec(c.th, c.sn, c.cs);
+    if (THETA) tn = theta_step(c.th, dth, FIRST); else tn = dth;
+    if (BN_ABLATE & 16) { c.sn = c.sn * 0.5f + dth; c.cs = 1.0f - c.sn; } else
+    rotate_spec(c.cs, c.sn, dth);
 }
 
 // One PlanetaryEnv.step (planetary_env.py:189-219) for instance b: observation-mode transit with the
@@ -313,13 +327,13 @@ __device__ __forceinline__ void slip_chain_step(const SolveParams &p, const floa
     const float2 ms = win2[c.e];
     const float trav = trav_from_slip(ms.x, ms.y, z);                  // robot_model.py:75
     const float tv = trav * u0;
-    tn = c.th + (trav * u1) * p.dt;
+    const float dth = (trav * u1) * p.dt;
     xn = c.x + (tv * c.cs) * p.dt;
     yn = c.y + (tv * c.sn) * p.dt;
-    c.th = FIRST ? wrap_angle(tn) : wrap_angle_near(tn);
+    tn = theta_step(c.th, dth, FIRST);
     c.x = clampf(xn, p.x0, p.x_hi);
     c.y = clampf(yn, p.y0, p.y_hi);
-    sincos_spec(c.th, c.sn, c.cs);
+    rotate_spec(c.cs, c.sn, dth);                                      // carried heading vector (bn_device_math.h)
     c.e = slip_cell_window<GEO>(p, w, c.x, c.y);
 }
 
@@ -801,15 +815,17 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
                 BN_STAMP(11);
             } else {
                 float x = sx, y = sy, th = sth;
+                float sn, cs;
+                sincos_spec(th, sn, cs);
                 for (int t = 0; t < T; ++t) {
                     const int e = slip_cell_safe<GEO, false>(p, w, x, y);
                     const float trav = trav_from_slip(map[e], sg[e], zol[t]);
-                    float sn, cs;
-                    sincos_spec(th, sn, cs);
+                    const float dth = (trav * us[2 * t + 1]) * p.dt;
                     xn = x + ((trav * us[2 * t]) * cs) * p.dt; yn = y + ((trav * us[2 * t]) * sn) * p.dt;
-                    tn = th + (trav * us[2 * t + 1]) * p.dt;
+                    tn = theta_step(th, dth, t == 0);
+                    rotate_spec(cs, sn, dth);
                     Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
-                    x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
+                    x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi);
                 }
                 Xs[3 * T] = x; Xs[3 * T + 1] = y; Xs[3 * T + 2] = th;
             }

@@ -48,6 +48,8 @@ struct SolveParams {
     uint64_t solve;      // index of this solve in the handle's life = Philox stream position
     int mean_from_part;  // rollout blocks merge part_prev themselves instead of reading `mean`
     int have_prev;       // the launch carries an aux workgroup per instance: tail of the previous solve
+    int self_tail;       // ... and a second one per instance: the tail of THIS solve (last launch of an overlapped batch, latency
+                         // kernel): it waits on the device for the rollout workgroups of its own launch instead of for a kernel boundary
     const float *map;    // (n_maps, G, G)
     const float *state;  // (B, 3)
     const float *goal;   // (B, 2)
@@ -98,6 +100,8 @@ struct SolveParams {
     unsigned long long *flag_tail;       // [B] tails (aux workgroups / finish kernels) of instance b completed, ever
     unsigned long long wait_part;        // flag_part[prev_slot][b] value that means "the previous solve's partials and costs of this instance are all there"
     unsigned long long wait_tail;        // flag_tail[b] value that means "the tail before the one this launch carries is done"
+    unsigned long long wait_part_self;   // self_tail: flag_part[cur_slot][b] value that means "this launch's rollout workgroups have all published"
+    unsigned long long wait_tail_self;   // self_tail: flag_tail[b] value that means "every earlier tail (incl. the one this launch carries) is done"
     int *err;                            // pinned host memory: set non-zero (system-scope store) when a bounded wait expired
     float *mean_snap;                    // (B, T, 2) or nullptr: workgroup 0 of every instance keeps the mean this solve samples around
                                          // (first launch since the host last checked `err`: where a re-run would start from)
@@ -123,7 +127,8 @@ inline dim3 rollout_grid(const SolveParams &p, bool aux)
 {
     const unsigned gx = (unsigned)p.nblk << p.xs;
     const unsigned rows = ((unsigned)p.B + (1u << p.xs) - 1) >> p.xs;
-    const unsigned aux_rows = aux ? ((unsigned)p.B + gx - 1) / gx : 0;
+    const unsigned n_aux = (aux ? (unsigned)p.B : 0u) + (p.self_tail ? (unsigned)p.B : 0u);      // previous tails first, then the own ones
+    const unsigned aux_rows = (n_aux + gx - 1) / gx;
     return dim3(gx, rows + aux_rows);
 }
 

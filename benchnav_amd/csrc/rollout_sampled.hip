@@ -209,6 +209,8 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
     for (int t = 0; t < T; t += 2) produce_pair<EPS, STORE_U>(p, p.eps, b, kk, t, p.solve, ml, Ul, Ub, Kp, lane);
     __syncthreads();
     float x = sx, y = sy, th = sth;
+    float sn, cs;
+    sincos_spec(th, sn, cs);
     float zq[4] = {0.f, 0.f, 0.f, 0.f};
     double Sd = 0.0, Ad = 0.0;
     for (int t = 0; t < T; ++t) {
@@ -221,12 +223,13 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         const float u0 = Ul[(2 * t) * kUPad + lane], u1 = Ul[(2 * t + 1) * kUPad + lane];
         const int e = slip_cell_safe<GEO, false>(p, w, x, y);
         const float trav = trav_from_slip(mu[e], sg[e], zq[t & 1]);                                     // robot_model.py:75
-        float sn, cs;
-        sincos_spec(th, sn, cs);
-        const float xn = x + ((trav * u0) * cs) * p.dt, yn = y + ((trav * u0) * sn) * p.dt, tn = th + (trav * u1) * p.dt;
+        const float dth = (trav * u1) * p.dt;
+        const float xn = x + ((trav * u0) * cs) * p.dt, yn = y + ((trav * u0) * sn) * p.dt;
+        const float tn = theta_step(th, dth, t == 0);
+        rotate_spec(cs, sn, dth);                                                                       // carried heading vector
         float *Xt = Xb + (size_t)(3 * t) * Kp;
         Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;
-        x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi); th = wrap_angle(tn);
+        x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi);
         // stage cost on the aliased slot: its own, independent slip draw (objectives.py:50)
         const int ec = slip_cell_safe<GEO, false>(p, w, xn, yn);
         const float tc = trav_from_slip(mu[ec], sg[ec], zq[2 + (t & 1)]);

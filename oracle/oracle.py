@@ -15,7 +15,8 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 TRIG_LIBM = 0
-TRIG_SPEC = 1
+TRIG_SPEC = 1            # the spec: heading vector carried by rotation within a rollout (oracle/mppi_oracle.c)
+TRIG_SPEC_PER_STEP = 2   # rounds 1-2: bn_sincos_spec of every step's heading
 
 
 class OracleParams(C.Structure):
@@ -139,6 +140,13 @@ def sincos(x, trig=TRIG_SPEC):
     s = np.empty_like(x); c = np.empty_like(x)
     lib().oracle_sincos(C.c_int32(trig), C.c_int64(x.size), _fp(x), _fp(s), _fp(c))
     return s, c
+
+
+def rotate(d, cs, sn):
+    """(cs, sn) <- R(d)(cs, sn) by the spec's small-angle rotation; arrays of equal size. Returns new (cs, sn)."""
+    d = _f32(d).ravel(); cs = _f32(cs).ravel().copy(); sn = _f32(sn).ravel().copy()
+    lib().oracle_rotate(C.c_int64(d.size), _fp(d), _fp(cs), _fp(sn))
+    return cs, sn
 
 
 def dwa(p: OracleParams, R, state, actions, sub_goal=None):
