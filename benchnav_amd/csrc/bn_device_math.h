@@ -70,8 +70,16 @@ __device__ __forceinline__ void rotate_spec(float &cs, float &sn, float d)
     pq = __builtin_elementwise_fma(dd, pq, v2f{-0.5f, -0.16666667163372040f});
     pq = __builtin_elementwise_fma(dd, pq, v2f{1.0f, 1.0f});                  // (cos d, sin d / d)
     const float sd = d * pq.y;
-    const v2f t = v2f{-sn, cs} * v2f{sd, sd};                                  // (-(sn*sd), cs*sd): the negation is exact
-    const v2f r = __builtin_elementwise_fma(v2f{cs, sn}, v2f{pq.x, pq.x}, t);
+    const v2f h = {cs, sn};
+    const v2f u = h * v2f{sd, sd};                                             // (cs*sd, sn*sd)
+    // (cs, sn) * cd + (-(sn*sd), cs*sd): the swap and the (exact) negation of the addend ride on the packed FMA's operand
+    // selectors -- spelled out, the compiler forms (-sn, cs) with a v_xor and a v_mov first, two more issue slots per step
+    v2f r;
+#ifdef BN_VAR_NO_ROTATE_ASM
+    r = __builtin_elementwise_fma(h, v2f{pq.x, pq.x}, v2f{-u.y, u.x});
+#else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_lo:[0,0,1]" : "=v"(r) : "v"(h), "v"(pq), "v"(u));
+#endif
     cs = r.x;
     sn = r.y;
 }

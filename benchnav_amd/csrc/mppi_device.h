@@ -479,6 +479,12 @@ __device__ __forceinline__ float block_reduce(float v, float *red, int tid, bool
 constexpr int kMergePrefetch = 16;
 struct MergeLoads { float v[kMergePrefetch]; float mi, si; int j; };
 
+// Which column of U* a thread of an NT-thread workgroup merges: its own index, rotated by c0 threads.  The latency kernel gives the
+// columns to the waves that have a SIMD to themselves (c0 = 128: waves 2 and 3 take 2T <= 128 columns; waves 0 and 4 share a SIMD and
+// were the last to reach the barrier behind the merge by 0.5 us, tools/stamps_overlap.py).  Who merges a column does not change its bits.
+template <int NT>
+__device__ __forceinline__ int merge_column(int tid, int c0) { return tid >= c0 ? tid - c0 : tid + NT - c0; }
+
 // Issue every load of the few-blocks merge (nblk <= 64) without consuming any: lets the caller put
 // other memory traffic (the window staging) in flight underneath.
 template <bool AGENT = false>
@@ -500,12 +506,13 @@ __device__ __forceinline__ MergeLoads merge_issue(const float *__restrict__ part
 
 // The same loads from the granule copy of the rows (nblk <= kMergePrefetch), each checked against the producing solve's tag:
 // `ok` stays true only if every granule this thread needs carried it.
-__device__ __forceinline__ MergeLoads merge_issue_granules(const unsigned long long *__restrict__ grows, int nblk, int T, int tid, uint32_t tag, bool &ok)
+// `col`: the column this thread merges (merge_column: not necessarily its thread index).
+__device__ __forceinline__ MergeLoads merge_issue_granules(const unsigned long long *__restrict__ grows, int nblk, int T, int tid, uint32_t tag, bool &ok, int col)
 {
     const int PS = 2 + 2 * T;
     const int lane = tid & 63;
     MergeLoads L;
-    L.j = tid < 2 * T ? tid : 0;
+    L.j = col < 2 * T ? col : 0;
     ok = true;
 #pragma unroll
     for (int i = 0; i < kMergePrefetch; ++i) L.v[i] = load_granule(grows + (size_t)min(i, nblk - 1) * PS + 2 + L.j, tag, ok);
@@ -570,8 +577,10 @@ __device__ __forceinline__ void merge_group(const float *__restrict__ part, int 
 // (the role and one-wave kernels, whose occupancy hangs on ~80 VGPRs and no scratch segment: tests/test_build_artifacts.py).
 template <int NT, bool AGENT = false, bool BIG = false, bool SYNC = true, bool WIDE = false>
 __device__ __forceinline__ void merge_partials(const float *__restrict__ part, int nblk, int T, float *us, float *sc,
-                                               float *red, int tid, float &m_out, float &S_out, bool have_pre, const MergeLoads &pre)
+                                               float *red, int tid, float &m_out, float &S_out, bool have_pre, const MergeLoads &pre,
+                                               int c0 = 0)
 {
+    const int col = merge_column<NT>(tid, c0);
 #define BN_PLD(ix) (AGENT ? load_agent(part + (ix)) : part[(ix)])
     const int PS = 2 + 2 * T;
     const int lane = tid & 63;
@@ -588,7 +597,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
         // loop below, and a ds_bpermute shuffle returns nothing from the lanes that did not
         const int fb = __float_as_int(f);
 #define BN_SCALE(i) __int_as_float(__builtin_amdgcn_readlane(fb, (i)))
-        for (int jj = tid; jj < 2 * T; jj += NT) {
+        for (int jj = col; jj < 2 * T; jj += NT) {
             float acc = 0.0f;
             if (BN_VAR_SKIP & 4) { us[jj] = L.v[0] * 1e-3f; continue; }
             int i0 = 0;
