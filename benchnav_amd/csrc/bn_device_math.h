@@ -128,6 +128,21 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi)
 // value by value against IEEE sqrt, denormals included.
 __device__ __forceinline__ float sqrt_cr(float x) { return sqrtf(x); }
 
+// The same value for x == 0 and 2^-96 <= x < inf -- squared distances between float positions on a map are zero or at least
+// (one ulp of a coordinate)^2 >= 2^-68 --, without the compiler's scaling of small arguments and its inf / nan pass-through: v_sqrt_f32
+// (at most one ulp off), then the neighbour below / above is taken when the residual x - s' * s says it lies on the correct side.
+// Nine instructions instead of seventeen: consumer B's SIMD is the one that runs out of issue slots behind a fast chain.
+// tests/test_gpu_device_math.py checks it value by value against IEEE sqrt.
+__device__ __forceinline__ float sqrt_cr_normal(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    s = rm <= 0.0f ? sm : s;
+    s = rp > 0.0f ? sp : s;
+    return s;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
 {
     return min(max(v, lo), hi);

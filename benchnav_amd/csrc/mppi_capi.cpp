@@ -1063,7 +1063,10 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         BN_HIP(hipEventRecord(h->ev_fork, h->stream));              // (nothing is: no event packet in front of the first launches)
         for (int q = 0; q + 1 < S; ++q) BN_HIP(hipStreamWaitEvent(h->xstream[q], h->ev_fork, 0));
     }
-    static const bool exp_self_tail = std::getenv("BN_NO_SELF_TAIL") == nullptr;   // experiments (tools/region_overhead.py)
+    // The last launch of a long batch can carry its own tail as a second aux workgroup (SolveParams::self_tail) instead of a tail
+    // kernel behind it.  Measured (tools/region_overhead.py, K = 20): 0.7 us better with round 2's kernel, 5 us WORSE since the
+    // barrier-free prologue (225.2 vs 230.2 us) -- off unless BN_SELF_TAIL is set; the code stays for the next look at the region's ends.
+    static const bool exp_self_tail = std::getenv("BN_SELF_TAIL") != nullptr;
     static const bool exp_align = std::getenv("BN_NO_ALIGN") == nullptr;
     if (!exp_align) idle = false;                                   // (only the stream assignment below looks at it from here on)
     int rc = BN_OK;
@@ -1618,7 +1621,7 @@ void bn_mppi_debug_trace_by_parity(bn_mppi_t *h, int on) { h->p.trace_by_parity 
 
 int bn_device_math_eval(int32_t fn, const float *in_device, float *out_device, int64_t n, void *stream)
 {
-    if (fn < 0 || fn > 4 || !in_device || !out_device || n < 0) return fail(BN_ERR_INVALID, "bad argument");
+    if (fn < 0 || fn > 5 || !in_device || !out_device || n < 0) return fail(BN_ERR_INVALID, "bad argument");
     if (n == 0) return BN_OK;
     BN_HIP(bn::launch_math_eval(fn, in_device, out_device, (size_t)n, (hipStream_t)stream));
     return BN_OK;

@@ -182,7 +182,8 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
 }
 
 // Per-rollout recurrence state: the clamped/wrapped state t, its traversability, sin/cos of its heading.
-struct Chain { float x, y, th, sn, cs, trav; };
+// G, wq: what the next step can know before the traversability of its start cell arrives (chain_prepare).
+struct Chain { float x, y, th, sn, cs, trav; v2f G; float wq; };
 
 // The heading of a rollout as an OUTPUT: theta_{t+1} = wrap(theta_t + d_t) (robot_model.py:88,90), tn = the un-wrapped sum slot t
 // keeps.  The first step takes the general wrap (a caller's start heading may be anything), later ones the near form.
@@ -200,17 +201,30 @@ __device__ __forceinline__ float theta_step(float &th, float dth, bool first)
 // THETA = false (the role kernels' chain wave) tn returns the step's heading increment d_t instead and c.th is not touched:
 // the wave that stores the trajectory integrates theta from the increments (theta_step).
 // u0, u1 already lie in [u_min, u_max]: the re-clamp of robot_model.py:82-83 is the identity.
-template <int GEO, bool LDSWIN, bool FIRST, bool THETA = true>
-__device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
-                                           const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn)
+// Arithmetic of one transit (DESIGN.md "Arithmetic spec"): with g = v dt and w = omega dt (the controls, pre-scaled),
+//   x~ = fma(trav, g cos, x)   y~ = fma(trav, g sin, y)   d = trav w   theta~ = theta + d
+// -- the reference's ((trav v) cos) dt + x with one rounding fewer and everything but `trav` folded into factors that are ready
+// before the gather returns: ONE dependent instruction between the traversability and the new position instead of four.
+__device__ __forceinline__ void chain_prepare(const SolveParams &p, Chain &c, float u0, float u1)
 {
+    const float g = u0 * p.dt;
+    c.wq = u1 * p.dt;
+    c.G = v2f{g, g} * v2f{c.cs, c.sn};
+}
+
+// PREP: the caller's loop hands over the NEXT step's controls (u0n, u1n) and chain_prepare runs for them at the end of this step,
+// under the gather's latency (the role kernels' chain wave); otherwise the step prepares itself from its own controls first.
+template <int GEO, bool LDSWIN, bool FIRST, bool THETA = true, bool PREP = false>
+__device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
+                                           const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn,
+                                           float u0n = 0.0f, float u1n = 0.0f)
+{
+    if (!PREP) chain_prepare(p, c, u0, u1);
     // Position strand first: update, clamp, cell index, and the gather goes out; the heading strand (rotation, 7
     // instructions) then runs under the gather's LDS latency.  The scheduling barrier keeps the compiler from
     // interleaving the two again (it used to issue the gather two thirds into the step).
-    const float tv = c.trav * u0;
-    const float dth = (c.trav * u1) * p.dt;
-    // x and y advance in lockstep: packed multiply / multiply / add (same roundings as the scalar form)
-    const v2f pos = v2f{c.x, c.y} + (v2f{tv, tv} * v2f{c.cs, c.sn}) * v2f{p.dt, p.dt};   // :86-87
+    const float dth = c.trav * c.wq;                                   // :88
+    const v2f pos = __builtin_elementwise_fma(v2f{c.trav, c.trav}, c.G, v2f{c.x, c.y});   // :86-87, x and y in lockstep
     xn = pos.x;
     yn = pos.y;
     c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
@@ -221,6 +235,7 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     if (THETA) tn = theta_step(c.th, dth, FIRST); else tn = dth;
     if (BN_ABLATE & 16) { c.sn = c.sn * 0.5f + dth; c.cs = 1.0f - c.sn; } else
     rotate_spec(c.cs, c.sn, dth);
+    if (PREP) chain_prepare(p, c, u0n, u1n);
 }
 
 // One PlanetaryEnv.step (planetary_env.py:189-219) for instance b: observation-mode transit with the
@@ -326,10 +341,10 @@ __device__ __forceinline__ void slip_chain_step(const SolveParams &p, const floa
 {
     const float2 ms = win2[c.e];
     const float trav = trav_from_slip(ms.x, ms.y, z);                  // robot_model.py:75
-    const float tv = trav * u0;
-    const float dth = (trav * u1) * p.dt;
-    xn = c.x + (tv * c.cs) * p.dt;
-    yn = c.y + (tv * c.sn) * p.dt;
+    const float g = u0 * p.dt;                                         // the transit arithmetic of chain_step
+    const float dth = trav * (u1 * p.dt);
+    xn = __builtin_fmaf(trav, g * c.cs, c.x);
+    yn = __builtin_fmaf(trav, g * c.sn, c.y);
     tn = theta_step(c.th, dth, FIRST);
     c.x = clampf(xn, p.x0, p.x_hi);
     c.y = clampf(yn, p.y0, p.y_hi);
@@ -524,6 +539,48 @@ __device__ __forceinline__ MergeLoads merge_issue_granules(const unsigned long l
     L.mi = has ? mi : -INFINITY;
     L.si = has ? si : 0.0f;
     return L;
+}
+
+// Split-phase form of merge_issue_granules: issue() puts the 18 loads of one poll on the wire, take() looks at them (the compiler's
+// vmcnt wait lands there, not at the issue).
+struct GranulePoll {
+    unsigned long long v[kMergePrefetch], mi, si;
+    __device__ __forceinline__ void issue(const unsigned long long *__restrict__ grows, int nblk, int T, int lane, int col)
+    {
+        const int PS = 2 + 2 * T;
+        const int j = col < 2 * T ? col : 0;
+#pragma unroll
+        for (int i = 0; i < kMergePrefetch; ++i)
+            v[i] = __hip_atomic_load(grows + (size_t)min(i, nblk - 1) * PS + 2 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mi = __hip_atomic_load(grows + (size_t)min(lane, nblk - 1) * PS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        si = __hip_atomic_load(grows + (size_t)min(lane, nblk - 1) * PS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // all of this lane's granules carry `tag`?  L: the values, laid out as merge_issue_granules leaves them
+    __device__ __forceinline__ bool take(uint32_t tag, int nblk, int T, int lane, int col, MergeLoads &L) const
+    {
+        bool ok = (uint32_t)(mi >> 32) == tag && (uint32_t)(si >> 32) == tag;
+#pragma unroll
+        for (int i = 0; i < kMergePrefetch; ++i) { ok = ok && (uint32_t)(v[i] >> 32) == tag; L.v[i] = __uint_as_float((uint32_t)v[i]); }
+        const bool has = lane < nblk;
+        L.mi = has ? __uint_as_float((uint32_t)mi) : -INFINITY;
+        L.si = has ? __uint_as_float((uint32_t)si) : 0.0f;
+        L.j = col < 2 * T ? col : 0;
+        return ok;
+    }
+};
+
+// U*[column L.j] from one thread's prefetched rows (nblk <= kMergePrefetch): the arithmetic of merge_partials' few-blocks branch,
+// operation for operation, for a caller that wants the value in a register instead of in LDS.  Every lane of the wave must call it.
+__device__ __forceinline__ float merge_one(const MergeLoads &L, int nblk, int lane)
+{
+    const float m = wave_max(L.mi);
+    const float f = lane < nblk ? expf(L.mi - m) : 0.0f;
+    const float S = wave_sum(L.si * f);
+    const int fb = __float_as_int(f);
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kMergePrefetch; ++i) acc = __builtin_fmaf(L.v[i], __int_as_float(__builtin_amdgcn_readlane(fb, i)), acc);   // f == 0 past nblk
+    return acc / S;
 }
 
 // Two-level merge for more than 64 partial rows (K > 4096): rows are first merged in groups of kGroupRows
@@ -829,8 +886,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
                 for (int t = 0; t < T; ++t) {
                     const int e = slip_cell_safe<GEO, false>(p, w, x, y);
                     const float trav = trav_from_slip(map[e], sg[e], zol[t]);
-                    const float dth = (trav * us[2 * t + 1]) * p.dt;
-                    xn = x + ((trav * us[2 * t]) * cs) * p.dt; yn = y + ((trav * us[2 * t]) * sn) * p.dt;
+                    const float g = us[2 * t] * p.dt, dth = trav * (us[2 * t + 1] * p.dt);
+                    xn = __builtin_fmaf(trav, g * cs, x); yn = __builtin_fmaf(trav, g * sn, y);
                     tn = theta_step(th, dth, t == 0);
                     rotate_spec(cs, sn, dth);
                     Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;

@@ -313,6 +313,7 @@ __global__ void math_eval_kernel(int fn, const float *__restrict__ in, float *__
         case 0: r = sqrt_cr(x); break;
         case 1: sincos_spec(x, sn, cs); r = sn; break;
         case 2: sincos_spec(x, sn, cs); r = cs; break;
+        case 5: r = sqrt_cr_normal(x); break;
         case 3: r = wrap_angle(x); break;
         default: r = wrap_angle_near(x); break;
         }
@@ -386,10 +387,10 @@ size_t wave_lds_bytes(const SolveParams &p)
 
 size_t lat_lds_bytes(const SolveParams &p)
 {
-    // [ ring T x 64 x float4 | fin 5 x 64 | e 64 | progress 4 | window | mean 2T | mean*inv_var 2T | control tile 2T x 65 ]
+    // [ ring (T + 1) x 64 x float4 | fin 5 x 64 | e 64 | progress 4 | window | mean 2T | mean*inv_var 2T | control tile 2T x 65 ]
     if (p.WN <= 0) return 0;
     const size_t wcap = (size_t)p.WN + 2 * (size_t)p.spec_extra;
-    const size_t own = (size_t)p.T * 256 + 5 * 64 + 64 + 4 + wcap * wcap + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad;
+    const size_t own = ((size_t)p.T + 1) * 256 + 5 * 64 + 64 + 8 + wcap * wcap + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad;
     const size_t bytes = std::max(sizeof(float) * own, finish_lds_bytes(p) + 256);      // the aux workgroup runs finish_body in the same LDS
     return bytes <= 160 * 1024 ? bytes : 0;
 }

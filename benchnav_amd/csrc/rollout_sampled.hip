@@ -223,8 +223,8 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         const float u0 = Ul[(2 * t) * kUPad + lane], u1 = Ul[(2 * t + 1) * kUPad + lane];
         const int e = slip_cell_safe<GEO, false>(p, w, x, y);
         const float trav = trav_from_slip(mu[e], sg[e], zq[t & 1]);                                     // robot_model.py:75
-        const float dth = (trav * u1) * p.dt;
-        const float xn = x + ((trav * u0) * cs) * p.dt, yn = y + ((trav * u0) * sn) * p.dt;
+        const float g = u0 * p.dt, dth = trav * (u1 * p.dt);                                           // the transit arithmetic of chain_step
+        const float xn = __builtin_fmaf(trav, g * cs, x), yn = __builtin_fmaf(trav, g * sn, y);
         const float tn = theta_step(th, dth, t == 0);
         rotate_spec(cs, sn, dth);                                                                       // carried heading vector
         float *Xt = Xb + (size_t)(3 * t) * Kp;

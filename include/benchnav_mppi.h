@@ -351,7 +351,7 @@ const char *bn_risk_last_error(void);
 
 /* Test hook: the library's device arithmetic (DESIGN.md "Arithmetic spec") applied elementwise to n device floats:
  * fn 0 = correctly rounded sqrt, 1 / 2 = sin / cos of the spec, 3 = heading wrap (theta + pi) % 2pi - pi with
- * torch.remainder semantics (robot_model.py:90), 4 = its in-loop form.  Lets the tests compare the kernels' building
+ * torch.remainder semantics (robot_model.py:90), 4 = its in-loop form, 5 = the sqrt for zero / normal finite arguments.  Lets the tests compare the kernels' building
  * blocks with the oracle's one value at a time. */
 int bn_device_math_eval(int32_t fn, const float *in_device, float *out_device, int64_t n, void *stream);
 

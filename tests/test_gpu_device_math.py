@@ -32,6 +32,21 @@ def test_sqrt_is_correctly_rounded_everywhere_it_is_used():
     assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
 
 
+def test_the_short_sqrt_is_correctly_rounded_on_zero_and_normal_arguments():
+    """sqrt_cr_normal (the latency kernel's stage cost): no scaling of small arguments, no inf / nan pass-through.  Valid for
+    x == 0 and 2^-96 <= x < inf (below, the residuals of its correction step go denormal): squared distances between float
+    positions on a map are zero or >= (2^-24 * 2^-10)^2 = 2^-68.  The same bits as IEEE sqrt there."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([
+        rng.random(1 << 21).astype(np.float32) * np.float32(1e4),
+        np.exp(rng.uniform(np.log(1e-28), np.log(3e38), 1 << 21)).astype(np.float32),
+        (np.arange(1, 4097, dtype=np.float32) ** 2), (np.arange(1, 4097, dtype=np.float32) ** 2 + 1), (np.arange(2, 4097, dtype=np.float32) ** 2 - 1),
+        np.array([0.0, 1.0, 2.0, 2.0 ** -96, 2.0 ** -90, 1e-20, 3.4e38], np.float32)])
+    got = _eval(5, x)
+    want = np.sqrt(x.astype(np.float32))
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+
+
 def test_sincos_and_wrap_equal_the_oracle_bit_for_bit():
     from oracle import oracle as O
     rng = np.random.default_rng(1)

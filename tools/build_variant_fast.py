@@ -1,0 +1,33 @@
+"""Build tools/_ablate/lib_<name>.so where only the latency / role kernel of the Philox noise source (rollout_role_philox.hip) is
+compiled with the extra -D flags; every other object comes from a base set: the product's (benchnav_amd/lib/obj) or, with
+`--timing`, a -DBN_TIMING set built once into tools/_ablate/obj_timing (so that the stamp tools work on variants).  ~1 minute:
+    python tools/build_variant_fast.py [--timing] name -DBN_ABLATE=16 ..."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from benchnav_amd import build as b
+args = sys.argv[1:]
+timing = "--timing" in args
+args = [a for a in args if a != "--timing"]
+name, flags = args[0], args[1:]
+out_dir = os.path.join(ROOT, "tools", "_ablate")
+os.makedirs(out_dir, exist_ok=True)
+compile_flags = [f for f in b.HIPCC_FLAGS if f != "-shared"]
+base_dir = os.path.join(b.LIB_DIR, "obj")
+if timing:
+    flags = ["-DBN_TIMING"] + flags
+    base_dir = os.path.join(out_dir, "obj_timing")
+    os.makedirs(base_dir, exist_ok=True)
+    stale = [s for s in b.SOURCES if s != "rollout_role_philox.hip" and
+             (not os.path.exists(os.path.join(base_dir, os.path.splitext(s)[0] + ".o")) or
+              os.path.getmtime(os.path.join(base_dir, os.path.splitext(s)[0] + ".o")) < max(os.path.getmtime(os.path.join(b.CSRC, f)) for f in os.listdir(b.CSRC)))]
+    procs = [subprocess.Popen([b.hipcc(), *compile_flags, "-DBN_TIMING", "-x", "hip", "-c", os.path.join(b.CSRC, s), "-o",
+                               os.path.join(base_dir, os.path.splitext(s)[0] + ".o")]) for s in stale]
+    for pr in procs:
+        assert pr.wait() == 0
+obj = os.path.join(out_dir, f"role_philox_{name}.o")
+subprocess.check_call([b.hipcc(), *compile_flags, *flags, "-x", "hip", "-c", os.path.join(b.CSRC, "rollout_role_philox.hip"), "-o", obj])
+others = [os.path.join(base_dir, os.path.splitext(s)[0] + ".o") for s in b.SOURCES if s != "rollout_role_philox.hip"]
+out = os.path.join(out_dir, f"lib_{name}.so")
+subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o", out])
+print("built", out)

@@ -30,8 +30,8 @@ print(f"entry->granules seen {r[13]:.2f} | merge {r[14] - r[13]:.2f} | chunk0/1 
 print(f"granules stored (prev) -> seen (next) {r[16]:.2f} us | period {r[17]:.2f} us | entry-to-entry {r[18]:.2f} us | seen->stored {r[5] - r[13]:.2f} us")
 w = np.median(np.stack(wrows), axis=0)
 names = {7: "granules seen", 8: "merged (before barrier)", 9: "after barrier", 0: "at final barrier", 1: "after final barrier", 2: "cost done (wave 4)",
-         3: "at e barrier", 4: "after e barrier", 5: "column sums issued", 6: "published"}
-t0 = w[:, 7].min()
+         3: "at e barrier", 4: "after e barrier", 5: "column sums issued", 6: "published", 10: "chain: per-step phase / producers: done producing", 11: "chain: last step / producers: second job done"}
+t0 = w[:, 7][w[:, 7] > 0].min()          # (the fast prologue's consumers never look at the granules)
 print("per-wave cycle stamps of workgroup 0, us after the first wave saw its granules (waves: 0 consumer A, 1 chain, 2-3 producers, 4 consumer B)")
-for i in (7, 8, 9, 0, 1, 2, 3, 4, 5, 6):
+for i in (7, 8, 9, 10, 11, 0, 1, 2, 3, 4, 5, 6):
     print(f"  {names[i]:26s}", "  ".join(f"{(w[k, i] - t0) / 2400.0:7.2f}" if w[k, i] else "      -" for k in range(5)))
