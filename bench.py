@@ -408,6 +408,25 @@ def main():
                                                      float(np.linalg.norm(states[-1, 0, :2] - inst.goal.numpy()))],
                               "note": "bn_mppi_episode_async: state advanced on the device by the observation-mode "
                                       "transit with sampled slip (planetary_env.py:189-219); includes the final log copy"}
+        # ---- the operating point the reference itself states (test/test_mppi.py:121-169, tutorial 3.3): K=5000, T=50, 64x64 map at
+        # 0.5 m, CVaR-0.9 risk map, start (8,8) heading at the goal (24,24).  K = 5000 is ragged and above the ticket-merge switch ----
+        from benchnav_amd.risk import infer_risk_map
+        Kr, Gr = 5000, 64
+        risk_r = infer_risk_map(synth.smooth_risk_map(Gr, 9) * 0.7, synth.slip_std_map(Gr, 9), "cvar", 0.9, seed=0).cpu().numpy()
+        plr = NativeMPPI(horizon=T, num_samples=Kr, grid_size=Gr, resolution=RES, device_id=dev, stream=stream.cuda_stream)
+        plr.set_map(risk_r); plr.set_goal(np.array([24.0, 24.0], np.float32))
+        st_r = torch.tensor([8.0, 8.0, 0.7853981633974483], device="cuda")
+        s_r, ms_r = leg(plr, st_r, None, max(200, a.steps // 5))
+        bytes_r = plr.algorithmic_bytes(injected_noise=False)
+        plr.close()
+        out["reference_operating_point"] = {
+            "workload": f"the reference's own test / tutorial configuration (test/test_mppi.py:121-169): mppi_solve K={Kr} T={T} map={Gr}x{Gr} "
+                        f"at {RES} m, CVaR-0.9 risk map (risk-map kernel), dependent warm-started solves, fixed state",
+            "value": 1.0 / s_r, "unit": "solves/s", "us_per_solve": s_r * 1e6,
+            "roofline": dict(roof(bytes_r, ms_r, f"rollout_K{Kr}_T{T}_G{Gr}"),
+                             kernel="bn::rollout_kernel (role kernel, ticket merge by the last workgroup; previous tail as aux workgroup)"),
+            "parity": "tests/golden/ref5000.npz: three warm-started solves of the imported reference at this configuration, "
+                      "teacher-forced and free-running (tests/test_gpu_parity.py)"}
         # ---- BASELINE config 3: K=8192, T=50, slip sampled per lookup from Normal(mean, std) (Philox in-kernel) ----
         K3 = 8192
         pl3 = NativeMPPI(horizon=T, num_samples=K3, grid_size=G, resolution=RES, device_id=dev, sampled_slip=True, stream=stream.cuda_stream)

@@ -855,7 +855,12 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             }
             p.overlap = (h->prev_published && p.have_prev) ? 1 : 0;
             p.gran_prev = (p.overlap && p.lat_kernel) ? h->d_gran[prev3] : nullptr;
-            if (p.overlap) { st = on_stream; h->overlap_used = true; }
+            // every member of the batch runs where the round robin put it -- the first one too (no predecessor to wait for, but if it
+            // stayed on the handle's stream while the batch is aligned to END there, solves 0 and 1 would share that stream and solve 2,
+            // on the other one, would become eligible before solve 1 is even dispatched: for launches that fill the chip that is the
+            // starvation pattern described in bn_mppi_solve_n_async -- 64 instances lost the whole gain of overlapping, 27.5 vs 23.3 us)
+            if (on_stream) st = on_stream;
+            if (p.overlap) h->overlap_used = true;
             h->pub[cur3] += (unsigned long long)p.nblk;
             h->prev_published = true;
             if (self_tail && p.lat_kernel && !h->in_episode) {         // last solve of a batch: its own tail rides in the same launch

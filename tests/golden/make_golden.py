@@ -585,6 +585,10 @@ def main():
     pi = math.pi
     if sys.argv[1:] == ["boundary"]:
         return run_boundary_case()
+    if sys.argv[1:] == ["ref5000"]:
+        return run_case("ref5000", G=64, res=0.5, K=5000, T=50, risk_mean=smooth_risk_map(64, 9) * 0.7, risk_std=slip_std_map(64, 9),
+                        metric="cvar", confidence=0.9, start=[8.0, 8.0, pi / 4], goal=torch.tensor([24, 24]), thr=0.3, n_solves=3,
+                        x_stride=8, advance="follow")
     if sys.argv[1:] == ["instance"]:
         return run_instance_io_case()
     if sys.argv[1:] == ["sampled"]:
@@ -625,6 +629,13 @@ def main():
     # ragged sizes: K not a multiple of 64, T=1
     run_case("ragged", G=33, res=1.0, K=77, T=1, risk_mean=iid_risk_map(33, 6),
              start=[16.5, 16.5, 0.0], goal=torch.tensor([20.0, 16.0]), n_solves=2)
+    # THE operating point the reference states (test/test_mppi.py:121-169, tutorial 3.3): K=5000, T=50, 64x64 at 0.5 m, CVaR-0.9
+    # risk map, start (8, 8) heading at the goal (24, 24) as env.reset leaves it, int64 goal; three warm-started solves.  K = 5000 is
+    # ragged (78 x 64 + 8) and above the K > 4096 switch to the ticket merge.  (The GP prediction is not reproducible here -- gpytorch
+    # is absent -- so the predictive distribution is synthetic like every fixture's; everything downstream of it is the reference's.)
+    run_case("ref5000", G=64, res=0.5, K=5000, T=50, risk_mean=smooth_risk_map(64, 9) * 0.7, risk_std=slip_std_map(64, 9),
+             metric="cvar", confidence=0.9, start=[8.0, 8.0, pi / 4], goal=torch.tensor([24, 24]), thr=0.3, n_solves=3, x_stride=8,
+             advance="follow")
     # config 2 (north-star point): 256x256, K=1024, T=50, the bench instance; X/U stored for every 4th rollout
     inst = make_instance(256, seed=0, resolution=0.5)
     run_case("c2", G=256, res=0.5, K=1024, T=50, risk_mean=inst.risk, start=inst.start.tolist(),

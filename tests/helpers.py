@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["c1_basic", "c1_stuck", "c1_edge", "res03", "cvar", "var", "ragged", "c2", "c2_stuck"]
+CASES = ["c1_basic", "c1_stuck", "c1_edge", "res03", "cvar", "var", "ragged", "c2", "c2_stuck", "ref5000"]
 
 
 def load_case(name):

@@ -39,9 +39,11 @@ def test_fixture_cases_teacher_forced(name, lds_window):
             assert np.array_equal(pl.get_mean(), us[0]), "warm start must be U* unshifted (mppi.py:217)"
 
 
-def test_free_running_warm_start_tracks_the_reference():
-    """No teacher forcing: the planner's own U* feeds the next mean, as in the reference loop."""
-    fx = load_case("c1_basic")
+@pytest.mark.parametrize("name", ["c1_basic", "ref5000"])
+def test_free_running_warm_start_tracks_the_reference(name):
+    """No teacher forcing: the planner's own U* feeds the next mean, as in the reference loop.  ref5000 is the operating point the
+    reference states (test/test_mppi.py:121-169: K=5000 -- ragged, ticket merge --, T=50, 64x64 CVaR-0.9 map, three solves)."""
+    fx = load_case(name)
     with native_planner_for(fx) as pl:
         pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
         for i in range(int(fx["n_solves"])):
