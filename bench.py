@@ -64,6 +64,10 @@ def parse():
                     help="keep every launch on one stream (BN_FLAG_NO_OVERLAP): the configuration whose per-kernel duration rocprofv3 "
                          "reports directly; by default consecutive dependent solves overlap on two streams")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c2",
+                    help="c2 (default, the headline): BASELINE configs[1], one K=1024 instance per GPU.  c4: configs[3], 64 independent "
+                         "instances sharded over the ranks (64/N per GPU, one launch per step).  c5: configs[4], ONE K=16384, T=100, "
+                         "512x512 solve sharded by rollouts over the ranks (RCCL all-gather of the softmin partials per solve)")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher check without a GPU: spawn the ranks, rendezvous, gather, print who took part; no planning")
     return ap.parse_args()
@@ -142,13 +146,19 @@ def main():
     dev = local % ndev
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: a single rank goes through the collective path as well (RCCL group of one: init, barrier, device
+    # all-gather, object gather) -- what lets a 1-GPU box execute the code an 8-GPU launch runs
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_
         dist = dist_
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     coll_dev = torch.device("cuda", dev) if (dist is not None and backend == "nccl") else None
 
     def sync():
@@ -157,6 +167,14 @@ def main():
         torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
+    if a.workload != "c2":
+        out = run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
 
     def make_planner(inst, B=1, **kw):
         kw.setdefault("overlap", not a.no_overlap)
@@ -281,7 +299,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": med / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": repeats, "ms_per_step_min": float(job.min()) / a.steps * 1e3, "ms_per_step_max": float(job.max()) / a.steps * 1e3,
-            "world_size": world, "devices": names,
+            "world_size": world, "devices": names, "collective_backend": (dist.get_backend() if dist is not None else None),
             "per_rank_solves": [a.steps] * world, "per_rank_seconds": [float(x) for x in per_rank[:, r_med]],
             "host_cpu": host_cpu(),
             "config": {"workload": "BASELINE configs[1]: single 256x256 map, K=1024, T=50, one instance per GPU, "
@@ -458,6 +476,101 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev):
+    """--workload c4 / c5: the two BASELINE configurations that name 8 GPUs, same contract line (metric, value = whole-job rate,
+    barrier + synchronize around exactly K steps, max over ranks), one `roofline` per workload."""
+    import numpy as np
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    from benchnav_amd.sharding import ShardedMPPI, gather_times, shard_instances
+    repeats = max(1, min(50, -(-400 // max(a.steps, 1))))
+    names = [None] * world
+    me = f"rank {rank}: cuda:{dev} {torch.cuda.get_device_name(dev)}"
+    if dist is not None:
+        dist.all_gather_object(names, me)
+    else:
+        names = [me]
+    if a.workload == "c4":
+        total = 64
+        mine = shard_instances(total, world, rank)                 # instance ids (= map seeds) of this rank
+        B = len(mine)
+        insts = [synth.make_instance(G, seed=s, resolution=RES, jitter=True) for s in mine]
+        pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=dev, stream=stream.cuda_stream,
+                        overlap=not a.no_overlap)
+        for b, it in enumerate(insts):
+            pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
+        states = torch.stack([it.start for it in insts]).cuda()
+
+        def region(n):
+            sync(); t0 = time.perf_counter()
+            pl.solve_n_async_device(n, states.data_ptr()); pl.flush()
+            sync(); dt_ = time.perf_counter() - t0
+            pl.sync()
+            return dt_
+        region(max(a.warmup, 1))
+        walls = [region(a.steps) for _ in range(repeats)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record(stream); pl.solve_n_async_device(max(a.steps, 100), states.data_ptr()); e1.record(stream)
+        pl.flush(); torch.cuda.synchronize(); pl.sync()
+        kernel_ms = e0.elapsed_time(e1) / max(a.steps, 100)
+        alg = pl.algorithmic_bytes(injected_noise=False) * B
+        units_per_step, scaling = total, "strong"          # 64 instances in total whatever N: the total work is fixed
+        workload = (f"BASELINE configs[3]: {total} independent 256x256 instances (map seeds 0..{total - 1}), K={K}, T={T}, sharded "
+                    f"{total}/{world} per GPU, one launch of this rank's instances per step, dependent warm-started solves")
+        kernel = "bn::rollout_kernel (role kernel)" if B * 17 <= 4352 else "bn::rollout_wave_kernel"
+        par = f"instance sharding x{world}, no data-path collective"
+        pl.close()
+    else:
+        K5, T5, G5 = 16384, 100, 512
+        inst = synth.make_instance(G5, seed=0, resolution=RES)
+        sh = ShardedMPPI(horizon=T5, num_samples=K5, grid_size=G5, resolution=RES, device_id=dev, stream=stream.cuda_stream)
+        sh.planner.set_map(inst.risk.numpy()); sh.planner.set_goal(inst.goal.numpy())
+        st = inst.start.cuda()
+
+        def region(n):
+            sync(); t0 = time.perf_counter()
+            for _ in range(n):
+                sh.solve(st)
+            sync(); dt_ = time.perf_counter() - t0
+            sh.planner.sync()
+            return dt_
+        region(max(a.warmup, 1))
+        walls = [region(a.steps) for _ in range(repeats)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record(stream)
+        for _ in range(max(a.steps, 50)):
+            sh.solve(st)
+        e1.record(stream); torch.cuda.synchronize(); sh.planner.sync()
+        kernel_ms = e0.elapsed_time(e1) / max(a.steps, 50)
+        # this rank's share of the algorithmic bytes: its rollouts' trajectories and weights, the map, + the exchanged partials
+        alg = sh.planner.algorithmic_bytes(injected_noise=False) + 2 * (K5 // 64) * (2 + 2 * T5) * 4
+        units_per_step, scaling = 1, "strong"
+        workload = (f"BASELINE configs[4]: ONE solve K={K5}, T={T5}, {G5}x{G5} map sharded by rollouts ({K5 // world} per GPU): rollouts, "
+                    f"all-gather of the softmin partials ({(K5 // 64) * (2 + 2 * T5) * 4} B in total), merge + tail on every rank")
+        kernel = "bn::rollout_kernel (role kernel, shard) + all_gather_into_tensor + bn::finish_kernel"
+        par = f"rollout sharding x{world}, one RCCL all-gather of the softmin partials per solve" if dist is not None else "one rank, no process group"
+        sh.close()
+    per_rank = gather_times(walls, coll_dev)
+    job = per_rank.max(dim=0).values
+    med = float(job.median())
+    r_med = int((job - med).abs().argmin())
+    value = units_per_step * a.steps / med
+    if rank != 0:
+        return None
+    out = {"metric": "MPPI solve-steps/sec", "value": value, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": med / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic", "repeats": repeats, "world_size": world, "devices": names,
+           "per_rank_seconds": [float(x) for x in per_rank[:, r_med]], "host_cpu": host_cpu(),
+           "collective_backend": (dist.get_backend() if dist is not None else None),
+           "config": {"workload": workload, "parallelism": par, "noise": "philox in-kernel"},
+           "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms,
+                        "algorithmic_bytes_per_launch": alg, "note": "rank 0's launch; per-step time between HIP events on the launch stream"}}
+    if shared_gpu or (dist is not None and backend != "nccl"):
+        out["rehearsal"] = f"ranks shared {ndev} GPU(s), backend {backend}: not a scaling measurement"
+    return out
 
 
 def rehearse(rank, world, local, backend):

@@ -133,7 +133,7 @@ class ShardedMPPI:
         else:
             self.planner.shard_rollout_async_device(state_dev.data_ptr(), eps_dev.data_ptr(), _capi.BN_NOISE_DEVICE_KT2 if kind is None else kind)
         mine = self._partials_tensor()
-        if self.world == 1:
+        if self._dist is None:                           # no process group: one rank, nothing to exchange
             self._gathered.copy_(mine)
         else:
             # equal-sized all-gather (ragged shards are padded to the largest), then the valid rows in rank order

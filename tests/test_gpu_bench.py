@@ -26,7 +26,9 @@ def test_single_rank_line():
     assert out["n_gpus"] == 1 and out["world_size"] == 1 and out["steps"] == 20 and out["repeats"] == 100
     assert out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
     rf = out["roofline"]
-    assert rf["kernel_ms"] <= out["ms_per_step"]            # a kernel cannot take longer than the step it lives in
+    # the launch-to-launch time (HIP event pair around the same K launches, two extra packets in a 0.2 ms window) against the
+    # step time of the timed region: the same thing measured twice
+    assert rf["kernel_ms"] <= 1.05 * out["ms_per_step"]
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["peak_measured_copy"] > 1000.0
     assert out["value"] > 20000 and out["unit"] == "solves/s" and out["host_cpu"]["logical_cpus"] >= 1
     assert out["sustained"]["value"] > 20000
@@ -42,3 +44,30 @@ def test_gpus_2_self_launches_two_ranks_on_the_device():
     if share:
         assert "rehearsal" in out
     assert out["value"] > 10000
+
+
+def test_a_single_rank_goes_through_rccl_when_asked():
+    """BENCH_FORCE_DIST=1: init_process_group("nccl") with a world of one, barrier around the timed regions, the times gathered with
+    a device all-gather, the names with all_gather_object -- the code an 8-GPU launch runs, executed on the one GPU of the box."""
+    out = _bench(["--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"], {"BENCH_FORCE_DIST": "1"})
+    assert out["collective_backend"] == "nccl" and out["n_gpus"] == 1 and out["value"] > 20000 and "rehearsal" not in out
+
+
+@pytest.mark.parametrize("workload", ["c4", "c5"])
+def test_the_multi_gpu_workloads_on_one_rank_over_rccl(workload):
+    """--workload c4 (64 instances sharded over the ranks) and c5 (one K=16384 solve sharded by rollouts: ShardedMPPI, one
+    all_gather_into_tensor of the partials per solve) with a world of one over RCCL."""
+    out = _bench(["--workload", workload, "--steps", "10", "--warmup", "3"], {"BENCH_FORCE_DIST": "1"})
+    assert out["collective_backend"] == "nccl" and out["scaling"] == "strong" and out["steps"] == 10
+    assert ("configs[3]" if workload == "c4" else "configs[4]") in out["config"]["workload"]
+    rf = out["roofline"]
+    assert 0 < rf["frac"] < 1 and rf["kernel_ms"] > 0
+    assert out["value"] > (500000 if workload == "c4" else 5000)
+
+
+def test_the_multi_gpu_workloads_with_two_ranks_on_the_device():
+    import torch
+    share = {} if torch.cuda.device_count() >= 2 else {"BENCH_SHARE_GPU": "1", "BENCH_DIST_BACKEND": "gloo"}
+    for workload in ("c4", "c5"):
+        out = _bench(["--gpus", "2", "--workload", workload, "--steps", "6", "--warmup", "2"], share)
+        assert out["n_gpus"] == 2 and out["world_size"] == 2 and len(out["per_rank_seconds"]) == 2 and out["value"] > 1000

@@ -136,3 +136,47 @@ def test_two_process_sharded_solve_over_torch_distributed():
     assert got[0][3] == got[1][3] == us[0].tobytes()                   # three warm-started solves later: still bit-identical
     assert got[0][4] == got[1][4] == xs[0].tobytes()
     assert abs(got[0][5] + got[1][5] - 1.0) < 1e-4                     # the shards' weights sum to one
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from benchnav_amd import NativeMPPI, synth
+from benchnav_amd.sharding import ShardedMPPI
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=0, world_size=1)
+K, T, G = 4096, 50, 256
+inst = synth.make_instance(G, seed=4)
+st = inst.start.cuda()
+sh = ShardedMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=77)
+assert sh._dist is not None and not sh._host_backend and sh.world == 1
+sh.planner.set_map(inst.risk.numpy()); sh.planner.set_goal(inst.goal.numpy())
+outs = []
+for i in range(3):                                   # warm-started chain: every solve's exchange goes through all_gather_into_tensor
+    sh.solve(st)
+    us, xs = sh.results()
+    torch.cuda.synchronize(); sh.planner.sync()
+    outs.append((us.cpu().numpy().copy(), xs.cpu().numpy().copy()))
+sh.close()
+with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=77, pipeline=False) as pl:
+    pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+    for i in range(3):
+        us, xs = pl.solve(inst.start.numpy())
+        assert np.array_equal(us[0], outs[i][0]) and np.array_equal(xs[0], outs[i][1]), i
+dist.barrier(); dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK", dist.is_nccl_available())
+"""
+
+
+def test_sharded_solve_over_an_rccl_group_of_one():
+    """ShardedMPPI with torch.distributed initialised on backend "nccl" (= RCCL) and a world of one: the exchange runs through
+    all_gather_into_tensor on device memory -- the branch an 8-GPU job takes -- and the chain of three warm-started solves is
+    bit-identical to the unsharded planner's.  In a subprocess: the process group must not leak into the test session."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
