@@ -17,8 +17,11 @@ variant).  Inputs (map, goal, state, mean) are resident in HBM bef
 rank plans its own map seed (instance sharding, no data-path collective); RCCL carries only the barrier around the timed
 region and the final gather of the per-rank times.
 
-Timing: exactly K steps between barrier + synchronize on both sides, max over ranks -- repeated (`repeats`) so that a
-K of 20 is not a 0.3 ms sample; `ms_per_step` / `value` are the MEDIAN repeat, the min is reported beside it.
+Timing: exactly K steps bracketed by barrier + synchronize, max over ranks -- repeated (`repeats`) so that a K of 20 is not
+a 0.3 ms sample; `ms_per_step` / `value` are the MEDIAN repeat, the min is reported beside it.  Per rank and repeat: barrier,
+synchronize, clock, the K steps, synchronize, clock, barrier.  The closing barrier sits BEHIND the second clock reading: the
+job time of a repeat is the maximum over the ranks of intervals that start together, which is what a barrier in front of the
+clock would yield -- minus the collective's own latency (an RCCL barrier is ~130 us here, more than half of a 20-step region).
 
 Extra objects on the line:
   roofline      dominant kernel (rollout) against the HBM roofline: algorithmic bytes per launch over the kernel's mean
@@ -95,6 +98,16 @@ def spawn_ranks(a) -> int:
     return subprocess.call(cmd, env=env)
 
 
+_STDOUT_FD = None
+
+
+def emit(obj) -> None:
+    """The one JSON line, on the process's real stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_STDOUT_FD if _STDOUT_FD is not None else 1, line)
+
+
 def host_cpu():
     model, phys = "unknown", set()
     try:
@@ -117,6 +130,12 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(a))
+    # Exactly ONE line on stdout: libraries that write to file descriptor 1 themselves (RCCL prints a version banner there when a
+    # process group comes up) go to stderr from here on; the JSON line is written to the saved descriptor at the end.
+    global _STDOUT_FD
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -173,7 +192,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         return
 
     def make_planner(inst, B=1, **kw):
@@ -201,8 +220,10 @@ def main():
         if events:
             e1.record(stream)
         pl.flush()
-        sync_()
+        torch.cuda.synchronize()                         # this rank's K steps are complete ...
         wall = time.perf_counter() - t0
+        if sync_ is sync and dist is not None:
+            dist.barrier()                               # ... and the ranks meet again behind the clock (see the module docstring)
         pl.sync()            # outside the timed region: the library's own synchronisation point (checks the overlapped launches' error word)
         return wall, (e0.elapsed_time(e1) if events else None)
 
@@ -475,7 +496,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev):
@@ -506,7 +527,9 @@ def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, 
         def region(n):
             sync(); t0 = time.perf_counter()
             pl.solve_n_async_device(n, states.data_ptr()); pl.flush()
-            sync(); dt_ = time.perf_counter() - t0
+            torch.cuda.synchronize(); dt_ = time.perf_counter() - t0
+            if dist is not None:
+                dist.barrier()
             pl.sync()
             return dt_
         region(max(a.warmup, 1))
@@ -533,7 +556,9 @@ def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, 
             sync(); t0 = time.perf_counter()
             for _ in range(n):
                 sh.solve(st)
-            sync(); dt_ = time.perf_counter() - t0
+            torch.cuda.synchronize(); dt_ = time.perf_counter() - t0
+            if dist is not None:
+                dist.barrier()
             sh.planner.sync()
             return dt_
         region(max(a.warmup, 1))
@@ -595,8 +620,8 @@ def rehearse(rank, world, local, backend):
     else:
         used = None
     if rank == 0:
-        print(json.dumps({"rehearsal": True, "n_gpus": world, "world_size": world, "backend": used, "ranks": who,
-                          "gathered_shape": list(per_rank.shape), "slowest_per_repeat": [float(x) for x in per_rank.max(dim=0).values]}))
+        emit({"rehearsal": True, "n_gpus": world, "world_size": world, "backend": used, "ranks": who,
+                          "gathered_shape": list(per_rank.shape), "slowest_per_repeat": [float(x) for x in per_rank.max(dim=0).values]})
 
 
 def cpu_baseline(inst, seconds, default_threads):

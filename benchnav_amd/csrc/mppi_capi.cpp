@@ -145,6 +145,7 @@ struct bn_mppi {
     // extra ones; device counters carry the dependency (SolveParams.flag_part / flag_tail)
     int n_streams = 1;
     hipStream_t xstream[kMaxStreams - 1] = {};
+    std::vector<hipStream_t> parked;            // streams that turned out to share the handle's hardware queue (see bn_mppi_create)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams - 1] = {};
     unsigned long long *d_flags = nullptr;      // [kSlots][B] flag_part per slot and instance, [B] flag_tail per instance, then int err
     bool role_overlap = false;                  // the role kernel's launches of a batch may overlap too (see bn_mppi_solve_n_async)
@@ -606,6 +607,32 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         h->ticket_mode = true;             // p.ticket stays null in h->p: only the one-launch path selects the ticket kernel
     }
     if (rc == BN_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(BN_ERR_HIP, "hipDeviceSynchronize failed after allocation");
+    // Overlapped launches need the extra stream on ANOTHER hardware queue than the handle's stream.  HIP deals its streams onto a
+    // handful of queues in creation order, so whether a fresh stream shares the queue of the caller's stream depends on how many
+    // streams the process has created before -- a process that brought up RCCL first ran every dependent solve 5.5 us slower
+    // (15.2 instead of 9.6 us: both "streams" one queue, no overlap at all).  Ask the hardware: a kernel on the handle's stream
+    // waits (bounded) for a flag a kernel on the candidate sets; if it never sees it, the candidate is replaced by a fresh stream.
+    if (rc == BN_OK && may_overlap) {
+        int *probe = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 1) * bn::kFlagStride);      // the spare counter slot
+        for (int q = 0; rc == BN_OK && q + 1 < h->n_streams; ++q) {
+            for (int attempt = 0; attempt < 8; ++attempt) {
+                int seen = 0;
+                if (hipMemset(probe, 0, 2 * sizeof(int)) != hipSuccess || bn::launch_queue_probe(probe, h->stream, h->xstream[q]) != hipSuccess ||
+                    hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->xstream[q]) != hipSuccess ||
+                    hipMemcpy(&seen, probe + 1, sizeof seen, hipMemcpyDeviceToHost) != hipSuccess) {
+                    (void)hipGetLastError();
+                    rc = fail(BN_ERR_HIP, "probing the streams of overlapped launches failed");
+                    break;
+                }
+                if (seen) break;
+                hipStream_t fresh = nullptr;
+                if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+                h->parked.push_back(h->xstream[q]);        // kept alive until destroy: destroying it would hand its queue slot to the next one
+                h->xstream[q] = fresh;
+            }
+        }
+        (void)hipMemset(probe, 0, 2 * sizeof(int));
+    }
     if (rc != BN_OK) {
         bn_mppi_destroy(h);
         return rc;
@@ -644,6 +671,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
         if (h->xstream[q]) { (void)hipStreamSynchronize(h->xstream[q]); (void)hipStreamDestroy(h->xstream[q]); }
         if (h->ev_join[q]) (void)hipEventDestroy(h->ev_join[q]);
     }
+    for (hipStream_t ps : h->parked) (void)hipStreamDestroy(ps);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->h_err) (void)hipHostFree(h->h_err);

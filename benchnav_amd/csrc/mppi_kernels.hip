@@ -524,6 +524,25 @@ hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipSt
     return hipGetLastError();
 }
 
+// ---- do two streams run concurrently? (bn_mppi_create: the extra stream of overlapped launches must not share a hardware queue
+// with the handle's stream) ----
+__global__ void queue_probe_wait_kernel(int *flag, int *seen)
+{
+    for (int it = 0; it < 4000; ++it) {                 // ~1.5 ms at most
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { *seen = 1; return; }
+        __builtin_amdgcn_s_sleep(14);
+    }
+    *seen = 0;
+}
+__global__ void queue_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter)
+{
+    queue_probe_wait_kernel<<<1, 1, 0, waiter>>>(flag_and_seen, flag_and_seen + 1);
+    queue_probe_set_kernel<<<1, 1, 0, setter>>>(flag_and_seen);
+    return hipGetLastError();
+}
+
 hipError_t launch_states_to_reference(const float *X_soa, float *X_aos, int K, int Kp, int T1, hipStream_t s)
 {
     soa_to_aos_kernel<<<grid_for((size_t)K * T1 * 3), 256, 0, s>>>(X_soa, X_aos, K, Kp, T1 * 3);
