@@ -29,6 +29,12 @@ elif base == "sampled":
     pl = NativeMPPI(horizon=T, num_samples=8192, grid_size=G, resolution=RES, sampled_slip=True, stream=0)
     pl.set_map(inst.risk.numpy()); pl.set_slip_std(synth.slip_std_map(G, seed=0).numpy()); pl.set_goal(inst.goal.numpy())
     st = inst.start.cuda()
+elif base == "ref5000":
+    from benchnav_amd.risk import infer_risk_map
+    risk = infer_risk_map(synth.smooth_risk_map(64, 9) * 0.7, synth.slip_std_map(64, 9), "cvar", 0.9, seed=0).cpu().numpy()
+    pl = NativeMPPI(horizon=T, num_samples=5000, grid_size=64, resolution=RES, stream=0, lean=lean)
+    pl.set_map(risk); pl.set_goal([24.0, 24.0])
+    st = torch.tensor([8.0, 8.0, 0.7853981633974483], device="cuda")
 elif base == "c5":
     inst = synth.make_instance(512, seed=0, resolution=RES)
     pl = NativeMPPI(horizon=100, num_samples=16384, grid_size=512, resolution=RES, stream=0, lean=lean)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-2 rocprofv3 evidence on the GPU box: tools/profile_r2.sh <tag> <commit>
+# rocprofv3 evidence on the GPU box (round 3; round 2's script with the reference operating point added): tools/profile_round3.sh <tag> <commit>
 #   kernel trace + stats of the bench command; FETCH_SIZE / WRITE_SIZE in separate --pmc passes, ONE bench leg per pass
 #   (tools/pmc_case.py), no trace domains mixed in; SQ counters of the single-instance and the 64-instance launch.
 set -u
-TAG=${1:-r2x}; COMMIT=${2:-unknown}
+TAG=${1:-r3x}; COMMIT=${2:-unknown}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT/pmc
@@ -15,7 +15,7 @@ DB=$(find $OUT/trace -name "*.db" | head -1)
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace1 -o t -- python $REPO/bench.py --no-cpu-baseline --no-overlap --steps 1000 --warmup 100 > $OUT/${TAG}_bench_profiled_no_overlap.json 2> $OUT/trace1.err
 DB=$(find $OUT/trace1 -name "*.db" | head -1)
 [ -n "$DB" ] && python $REPO/tools/rocpd_summary.py stats $DB $OUT/${TAG}_kernel_stats_no_overlap.csv || tail -5 $OUT/trace1.err
-for c in B1 B1_lean B64 B64_lean B256 B256_lean sampled c5; do
+for c in B1 B1_lean B64 B64_lean B256 B256_lean sampled c5 ref5000; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     k=$( [ $ctr = FETCH_SIZE ] && echo fetch || echo write )
     timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/p_${c}_$k -o p -- python $REPO/tools/pmc_case.py $c > $OUT/p_${c}_$k.log 2>&1
