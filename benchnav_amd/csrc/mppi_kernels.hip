@@ -381,7 +381,7 @@ hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
 
 size_t wave_lds_bytes(const SolveParams &p)
 {
-    const size_t own = (size_t)p.WN * p.WN + 4 * (size_t)p.T + 64 + (size_t)p.nblk + 32;
+    const size_t own = (size_t)p.WN * p.WN + 4 * (size_t)p.T + 64 + (size_t)p.nblk + 32 + 8 * kUPad;   // + the epilogue's control tile (kRegenCols columns)
     return std::max(sizeof(float) * own, finish_lds_bytes(p) + 256);      // the aux workgroup runs finish_body in the same LDS
 }
 

@@ -18,6 +18,8 @@ namespace {
 // Same device functions in the same order per rollout: results are bit-identical to the role kernel.
 // grid = rollout_grid, block = 64.  LDS: [ window | mean 2T | mean*inv_var 2T | e 64 | merge scratch ].
 // ------------------------------------------------------------------------------
+constexpr int kRegenCols = 8;            // columns (= 4 steps) of the control tile the noise-regenerating epilogue works on at a time
+
 template <int EPS, int GEO, bool LDSWIN>
 __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
 {
@@ -36,6 +38,15 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     float *mv = ml + 2 * T;
     float *el = mv + 2 * T;
     float *sc = el + 64;                              // merge scratch: nblk scales + 32
+    // REGEN (the library's own noise): the epilogue draws the noise again instead of reading the controls back from HBM.  The round
+    // trip -- (T,2,Kp) floats out and back per instance, 105 MB + 105 MB at 256 instances -- made this kernel bandwidth-bound in
+    // both modes (392 MB per launch against 229 MB algorithmic with the trajectory dump, 231 MB against 69 MB without); a Philox
+    // block costs VALU slots.  Measured, 256 instances, overlapped launches: 71.7 -> 64.3 us per launch with the trajectory dump
+    // (3.57 -> 3.98 M solves/s; traffic 392 -> ~230 MB), but 49.2 -> 55.4 us in lean mode, where the trajectory stores are not there to
+    // compete for the bandwidth and the launch becomes VALU-bound -- so lean launches keep the round trip, and so does injected noise
+    // (reading eps again is the same bytes).
+    const bool REGEN = EPS == kEpsPhilox && p.lean == 0 && !(BN_VAR_SKIP & 32);
+    float *ut = sc + p.nblk + 32;                     // REGEN: control tile of one chunk, kRegenCols columns x kUPad
     const int lane = threadIdx.x, b = wg.b;
     const int k = wg.blk * kRolloutsPerBlock + lane;
     const bool active = k < K;
@@ -109,12 +120,12 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
         const float u0 = clampf(ml[2 * t] + p.sigma0 * e[0], p.umin0, p.umax0);          // mppi.py:152-157
         const float u1 = clampf(ml[2 * t + 1] + p.sigma1 * e[1], p.umin1, p.umax1);
         float *Ut = Ub + (size_t)(2 * t) * Kp;
-        Ut[0] = u0; Ut[Kp] = u1;
+        if (!REGEN || p.store_u) { Ut[0] = u0; Ut[Kp] = u1; }
         if (t == 0) BN_WAVE_STEP(true, t, u0, u1); else BN_WAVE_STEP(false, t, u0, u1);
         if (t + 1 < T) {
             const float v0 = clampf(ml[2 * t + 2] + p.sigma0 * e[2], p.umin0, p.umax0);
             const float v1 = clampf(ml[2 * t + 3] + p.sigma1 * e[3], p.umin1, p.umax1);
-            Ut[2 * Kp] = v0; Ut[3 * Kp] = v1;
+            if (!REGEN || p.store_u) { Ut[2 * Kp] = v0; Ut[3 * Kp] = v1; }
             BN_WAVE_STEP(false, t + 1, v0, v1);
         }
     }
@@ -137,6 +148,34 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
     if (lane == 0) {
         if (pub) { store_agent(part, zmax); store_agent(part + 1, esum); }
         else { part[0] = zmax; part[1] = esum; }
+    }
+    if (REGEN) {
+        // weighted control sums, a chunk of kRegenCols / 2 steps at a time: every lane draws its controls of the chunk again (same
+        // Philox blocks, same clamp: the same bits), the chunk goes through a small LDS tile, and column_sums' own arithmetic --
+        // quarters of 16 rollouts summed in rollout order with fma, (q0 + q1) + (q2 + q3) by two DPP quad permutes -- adds it up
+        for (int t0 = 0; t0 < T; t0 += kRegenCols / 2) {
+#pragma unroll
+            for (int q = 0; q < kRegenCols / 4; ++q) {
+                const int t = t0 + 2 * q;
+                if (t < T) {
+                    float e2[4];
+                    noise_pair<EPS>(p, b, kk, t, e2);
+                    ut[(4 * q + 0) * kUPad + lane] = clampf(ml[2 * t] + p.sigma0 * e2[0], p.umin0, p.umax0);
+                    ut[(4 * q + 1) * kUPad + lane] = clampf(ml[2 * t + 1] + p.sigma1 * e2[1], p.umin1, p.umax1);
+                    if (t + 1 < T) {
+                        ut[(4 * q + 2) * kUPad + lane] = clampf(ml[2 * t + 2] + p.sigma0 * e2[2], p.umin0, p.umax0);
+                        ut[(4 * q + 3) * kUPad + lane] = clampf(ml[2 * t + 3] + p.sigma1 * e2[3], p.umin1, p.umax1);
+                    }
+                }
+            }
+            __syncthreads();
+            const int ncol = min(kRegenCols, 2 * (T - t0));
+            if (pub) column_sums<64, true>(ut, el, ncol / 2, lane, part + 2 * t0);
+            else column_sums<64, false>(ut, el, ncol / 2, lane, part + 2 * t0);
+            __syncthreads();                           // the tile is free again
+        }
+        if (pub) publish_counter(flag_ctr(p.flag_part, p.cur_slot * p.B + b), lane);
+        return;
     }
     // weighted control sums: lane = column j, whose 64 rollout values are one contiguous row of the (T,2,Kp) buffer
     const float *Urow0 = p.U + (size_t)b * T * 2 * Kp + (size_t)wg.blk * kRolloutsPerBlock;
