@@ -76,6 +76,7 @@ SYMBOLS = {
     "bn_mppi_dwa_buffers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bn_mppi_sync": (C.c_int, [_H]),
     "bn_mppi_recovery_count": (C.c_uint64, [_H]),
+    "bn_mppi_first_action": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_debug_expire_wait": (C.c_int, [_H]),
     "bn_mppi_flush": (C.c_int, [_H]),
     "bn_mppi_get_weights": (C.c_int, [_H, C.c_int32, _FP]),

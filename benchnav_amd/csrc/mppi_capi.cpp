@@ -165,6 +165,7 @@ struct bn_mppi {
     // synchronisation point, with the mean the first of them started from (kept by that launch itself, SolveParams::mean_snap)
     // and the solve counter (= Philox position) at that point -- what recover_overlap() needs to run them again on one stream.
     int *h_err = nullptr, *d_err = nullptr;     // host address / device address of the same word
+    unsigned long long *h_mail = nullptr, *d_mail = nullptr;   // (B, 2) granules {U*[0][d], solve index + 1}: see bn_mppi_first_action
     float *d_mean_snap = nullptr;
     struct BatchRec { int32_t n; const float *states; const float *eps; bn_noise_kind noise; int32_t eps_ring; int64_t eps_stride; bool episode; const float *z; };
     std::vector<BatchRec> journal;
@@ -559,6 +560,12 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         else if (hipHostGetDevicePointer((void **)&h->d_err, h->h_err, 0) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostGetDevicePointer failed");
         else *h->h_err = 0;
     }
+    if (rc == BN_OK) {
+        if (hipHostMalloc((void **)&h->h_mail, B * 2 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&h->d_mail, h->h_mail, 0) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostMalloc (first-action mailbox) failed");
+        else std::memset(h->h_mail, 0, B * 2 * sizeof(unsigned long long));
+    }
+    p.mail = h->d_mail;
     if (h->lat_kernel && p.nblk <= 16 && 2 * p.T <= bn::kRolloutThreads && !std::getenv("BN_NO_GRANULES"))
         for (int q = 0; q < kSlots; ++q) alloc(&h->d_gran[q], (B * (size_t)p.nblk * (2 + 2 * T) + 4 * B) * sizeof(unsigned long long));   // rows, then 4 per instance for the state
     // the role kernel (launches that do not leave every workgroup a CU of its own) overlaps its launches as well: a workgroup of
@@ -675,6 +682,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->h_err) (void)hipHostFree(h->h_err);
+    if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->d_mean_snap) (void)hipFree(h->d_mean_snap);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -854,6 +862,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         // one launch: merge + tail of the previous solve ride along with this solve's rollouts
         p.have_prev = h->tail_pending ? 1 : 0;
         p.mean_from_part = h->tail_pending ? 1 : 0;
+        p.tail_solve = p.solve - 1;                                   // the tail the aux workgroups write
         if (h->in_episode) {
             // closed loop: from the second step on, the rollout workgroups advance the state themselves
             p.env_on = 1;
@@ -1360,6 +1369,42 @@ int bn_mppi_sync(bn_mppi_t *h)
 }
 
 uint64_t bn_mppi_recovery_count(const bn_mppi_t *h) { return h ? h->recoveries : 0; }
+
+int bn_mppi_first_action(bn_mppi_t *h, int32_t instance, float action_host[2])
+{
+    if (int rc = check_instance(h, instance, false)) return rc;
+    if (!action_host) return fail(BN_ERR_INVALID, "null output");
+    if (h->solves == 0) return fail(BN_ERR_STATE, "no solve has run");
+    if (h->shard_pending) return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
+    BN_BIND(h);
+    if (int rc = flush_tail(h)) return rc;                  // the tail is what posts it
+    // The tail writes U*[0] to pinned host memory as soon as its merge is done -- two {value, tag} granules, tag = solve index + 1
+    // -- and goes on with X* and the weights; the host polls the granules: no stream synchronisation, no copy.
+    const uint32_t want = (uint32_t)h->solves;
+    const volatile unsigned long long *m = h->h_mail + 2 * (size_t)instance;
+    for (long it = 0;; ++it) {
+        const unsigned long long a = m[0], b = m[1];
+        if ((uint32_t)(a >> 32) == want && (uint32_t)(b >> 32) == want) {
+            const uint32_t ua = (uint32_t)a, ub = (uint32_t)b;
+            std::memcpy(action_host, &ua, 4); std::memcpy(action_host + 1, &ub, 4);
+            break;
+        }
+        if ((it & 0xfff) == 0xfff) {                        // every few microseconds: is the stream still working on it?
+            const hipError_t q = hipStreamQuery(h->stream);
+            (void)hipGetLastError();
+            if (q == hipSuccess && it > (1L << 22)) return fail(BN_ERR_HIP, "the stream is idle but the first action of solve %llu never arrived",
+                                                                 (unsigned long long)h->solves - 1);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(BN_ERR_HIP, "the stream failed while waiting for the first action");
+        }
+    }
+    if (h->overlap_used && __atomic_load_n(h->h_err, __ATOMIC_ACQUIRE)) {   // an expired wait upstream: repair, then read the repaired value
+        if (int rc = settle_point(h)) return rc;
+        const unsigned long long a = m[0], b = m[1];
+        const uint32_t ua = (uint32_t)a, ub = (uint32_t)b;
+        std::memcpy(action_host, &ua, 4); std::memcpy(action_host + 1, &ub, 4);
+    }
+    return BN_OK;
+}
 
 int bn_mppi_debug_expire_wait(bn_mppi_t *h)
 {

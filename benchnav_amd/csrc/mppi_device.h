@@ -434,6 +434,11 @@ __device__ __forceinline__ void store_granule(unsigned long long *ptr, float v, 
 {
     __hip_atomic_store(ptr, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ... to pinned host memory (system scope): what the host polls in bn_mppi_first_action
+__device__ __forceinline__ void store_granule_host(unsigned long long *ptr, float v, uint32_t tag)
+{
+    __hip_atomic_store(ptr, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ float load_granule(const unsigned long long *ptr, uint32_t tag, bool &ok)
 {
     const unsigned long long g = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -806,6 +811,10 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         }
     }
     if (tid == 0) {
+        if (p.mail) {                                  // the first control of U*, for the host that waits for it: out before anything else
+            store_granule_host(p.mail + 2 * b, us[0], (uint32_t)p.tail_solve + 1u);
+            store_granule_host(p.mail + 2 * b + 1, us[1], (uint32_t)p.tail_solve + 1u);
+        }
         st<AGENT>(p.stats + b * 2 + 0, m);
         st<AGENT>(p.stats + b * 2 + 1, S);
     }

@@ -110,6 +110,8 @@ struct SolveParams {
     float *w;            // (B, K)
     float *ustar;        // (B, T, 2)
     float *xstar;        // (B, T+1, 3)
+    unsigned long long *mail;   // (B, 2) pinned host memory: the tail posts U*[0] there as two {value, tag} granules the moment the merge is
+                                // done -- before the X* rollout and the weights -- for a host that consumes every solve (bn_mppi_first_action)
     float *out_copy;     // optional caller-owned copy of the packed (B,T,2) U* | (B,T+1,3) X* block, written by the same tail
                          // (bn_mppi_forward_async: the drop-in class's fresh output tensors without a second launch)
     float *stats;        // (B, 2): max z, sum exp

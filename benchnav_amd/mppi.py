@@ -197,6 +197,8 @@ class MPPI(nn.Module):
 
         self._buf_mean = self._wrap(_capi.BN_BUF_MEAN, (T, 2))
         self._cs = _CallState()
+        self.__dict__["_first_action_buf"] = None        # (plain attributes: nn.Module.__setattr__ is slow)
+        self.__dict__["_first_action_ptr"] = None
 
         if noise == "torch":
             # the reference constructor consumes one (K,T,2) draw of the global CPU stream (mppi.py:105-107)
@@ -337,6 +339,20 @@ class MPPI(nn.Module):
         return self._buf_ustar, self._buf_xstar
 
     solve = forward
+
+    def first_action(self) -> torch.Tensor:
+        """optimal_action_seq[0] of the latest forward() as a CPU tensor (2,), as early as it exists: the tail of the solve posts it
+        to pinned host memory right after the softmin merge, before it rolls out X* -- for a loop whose environment lives on the
+        host (test_mppi.py:181 hands action_seq[0, :] to env.step).  Same value as `optimal_action_seq[0].cpu()`, without the
+        stream synchronisation and the copy.  The returned tensor is reused by the next call."""
+        fa = self._first_action_buf
+        if fa is None:                                   # one CPU tensor, refilled by every call (clone it to keep a value)
+            fa = self.__dict__["_first_action_buf"] = torch.empty(2, dtype=self._dtype)
+            self.__dict__["_first_action_ptr"] = C.cast(fa.data_ptr(), C.POINTER(C.c_float))
+        rc = self._lib.bn_mppi_first_action(self._h, 0, self._first_action_ptr)
+        if rc:
+            _capi.check(rc)
+        return fa
 
     @property
     def _action_noises(self) -> Optional[torch.Tensor]:

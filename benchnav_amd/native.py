@@ -117,6 +117,12 @@ class NativeMPPI:
         else:
             _capi.check(self._lib.bn_mppi_set_mean(self._h, instance, _fp(_f32(mean, (self.T, 2)))))
 
+    def first_action(self, instance: int = 0) -> np.ndarray:
+        """U*[0] of the latest solve on the host, as soon as the tail has merged it (no stream synchronisation, no copy)."""
+        out = np.empty(2, np.float32)
+        _capi.check(self._lib.bn_mppi_first_action(self._h, instance, _fp(out)))
+        return out
+
     def get_mean(self, instance: int = 0) -> np.ndarray:
         out = np.empty((self.T, 2), np.float32)
         _capi.check(self._lib.bn_mppi_get_mean(self._h, instance, _fp(out)))

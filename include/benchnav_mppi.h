@@ -274,6 +274,11 @@ int bn_mppi_dwa_forward_async(bn_mppi_t *h, const float *states_device, float *p
 int bn_mppi_dwa_candidates(bn_mppi_t *h, int32_t num_actions, const float **actions_device, const float **stage_goal_device);
 /* Write the pending tail, wait for the handle's stream, check the overlapped launches' error word (see bn_mppi_solve_n_async). */
 int bn_mppi_sync(bn_mppi_t *h);
+/* optimal_action_seq[0] (mppi.py:219 -> test_mppi.py:181: what env.step consumes) of the latest solve, on the host, as early as it
+ * exists: the tail of a solve posts U*[0] to pinned host memory right after the softmin merge -- before it rolls out X* and
+ * normalises the weights -- and this call polls for it.  No stream synchronisation, no device-to-host copy; the other outputs are
+ * complete in stream order as always.  Enqueues the pending tail first (like every getter). */
+int bn_mppi_first_action(bn_mppi_t *h, int32_t instance, float action_host[2]);
 /* How many times this handle re-ran batches after an expired device-side wait (0 in normal operation). */
 uint64_t bn_mppi_recovery_count(const bn_mppi_t *h);
 /* Test hook: behave as if a bounded device-side wait had expired in the batches enqueued since the last synchronisation point

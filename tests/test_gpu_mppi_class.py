@@ -145,3 +145,30 @@ def test_forward_under_a_different_current_stream_is_fenced():
         U2, X2 = ref(base + 0.01 * i)
         torch.cuda.synchronize()
         assert torch.equal(got[0], U2) and torch.equal(got[1], X2), i
+
+
+def test_first_action_is_the_first_row_of_the_optimal_action_sequence():
+    """MPPI.first_action(): U*[0] from the tail's pinned host mailbox -- posted before X* and the weights exist -- equals
+    optimal_action_seq[0] of every forward(), for the drop-in class and for several instances of the NumPy-level planner."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    from helpers import load_case, mppi_for_fixture
+    fx = load_case("c1_basic")
+    solver = mppi_for_fixture(fx, noise="philox")
+    state = torch.tensor(fx["state_0"], device="cuda")
+    for _ in range(5):
+        U, X = solver(state)
+        a = solver.first_action().clone()
+        assert a.device.type == "cpu" and a.shape == (2,) and torch.equal(a, U[0].cpu())
+    B, G = 3, 64
+    insts = [synth.make_instance(G, seed=s) for s in range(B)]
+    with NativeMPPI(horizon=20, num_samples=256, grid_size=G, resolution=0.5, num_instances=B) as pl:
+        for b, it in enumerate(insts):
+            pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
+        st = torch.stack([it.start for it in insts]).cuda()
+        for n in (1, 4, 20):                             # single solves, a short batch, an overlapped batch with its own tail
+            pl.solve_n_async_device(n, st.data_ptr())
+            firsts = [pl.first_action(b) for b in range(B)]
+            pl.sync()
+            for b in range(B):
+                assert np.array_equal(firsts[b], pl.get_mean(b)[0]), (n, b)

@@ -20,9 +20,17 @@ for mode, copy, lean in (("torch", True, False), ("torch_device", True, False), 
         host += time.perf_counter() - t0
         a = U[0].cpu()                      # the reference loop reads action_seq[0] every step
     dt = (time.perf_counter() - t) / n
+    # the same step with the first action taken from the tail's host mailbox (MPPI.first_action): no synchronisation, no copy
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
+        U, X = solver(state)
+        a = solver.first_action()
+    dm = (time.perf_counter() - t) / n
+    assert torch.equal(a, U[0].cpu())
+    a = a.clone()
     # back-to-back forwards without a read-back: the rate the host can feed the GPU at
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): U, X = solver(state)
     torch.cuda.synchronize(); dq = (time.perf_counter() - t) / n
     print(f"noise={mode:12s} copy_outputs={copy!s:5s} lean={lean!s:5s}: forward() host {host / n * 1e6:6.1f} us | forward()+readback {dt * 1e6:6.1f} us "
-          f"({1 / dt:.0f} Hz) | back-to-back {dq * 1e6:6.1f} us", flush=True)
+          f"({1 / dt:.0f} Hz) | forward()+first_action() {dm * 1e6:6.1f} us ({1 / dm:.0f} Hz) | back-to-back {dq * 1e6:6.1f} us", flush=True)
