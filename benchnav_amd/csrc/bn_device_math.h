@@ -158,10 +158,11 @@ __device__ __forceinline__ uint64_t mul_wide_u32(uint32_t a, uint32_t b)
     return r;
 }
 
-__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
+template <int ROUNDS>
+__device__ __forceinline__ u32x4 philox4x32(u32x4 c, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         // one v_mad_u64_u32 per product (both halves; measured full rate, tools/ubench3.hip) instead of
         // v_mul_lo_u32 + v_mul_hi_u32 (each ~4.5 SIMD cycles per wavefront)
         const uint64_t p0 = mul_wide_u32(0xD2511F53u, c.x), p1 = mul_wide_u32(0xCD9E8D57u, c.z);
@@ -172,6 +173,19 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
     }
     return c;
 }
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) { return philox4x32<10>(c, k0, k1); }
+// The per-rollout streams (control noise, slip draws: one block per rollout and step pair, the hot ones) take EIGHT rounds:
+// Philox4x32-7 is the smallest variant that passes BigCrush (Salmon et al., SC'11: "Philox4x32-7 ... Crush-resistant"; ten is
+// the authors' default with a safety margin), and the noise is 35 % of the throughput kernel's VALU instructions and what the
+// latency kernel's producers spend their time on.  (Eight, not seven: with seven the register allocator gives one role-kernel
+// variant a 20-byte scratch segment -- the emergency slot tests/test_build_artifacts.py exists to catch: 23 -> 28 us per
+// 64-instance launch.)  The library's own stream is not part of the parity spec;
+// bn_mppi_get_philox_noise / bn_mppi_get_slip_noise regenerate exactly what the kernels consume.
+#ifndef BN_STREAM_ROUNDS
+#define BN_STREAM_ROUNDS 8
+#endif
+constexpr int kStreamRounds = BN_STREAM_ROUNDS;
 
 // Two independent standard normals from two 32-bit words (Box-Muller).  This is the library's own noise
 // stream, not part of the parity spec, so it uses the hardware transcendentals: v_log_f32, v_sqrt_f32 and
@@ -194,8 +208,8 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, fl
 __device__ __forceinline__ void philox_eps_pair(uint64_t seed, uint64_t solve, uint32_t b, uint32_t k,
                                                 uint32_t pair, float e[4])
 {
-    const u32x4 r = philox4x32_10(u32x4{k, pair, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
-                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    const u32x4 r = philox4x32<kStreamRounds>(u32x4{k, pair, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
+                                              (uint32_t)seed, (uint32_t)(seed >> 32));
     box_muller(r.x, r.y, e[0], e[1]);   // step 2*pair: (v, omega) noise
     box_muller(r.z, r.w, e[2], e[3]);   // step 2*pair+1
 }
@@ -205,8 +219,8 @@ __device__ __forceinline__ void philox_eps_pair(uint64_t seed, uint64_t solve, u
 // optimal rollout, whose block j holds the transit draws of steps 4j .. 4j+3.
 __device__ __forceinline__ void philox_slip_block(uint64_t seed, uint64_t solve, uint32_t b, uint32_t k, uint32_t j, float z[4])
 {
-    const u32x4 r = philox4x32_10(u32x4{k, j, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
-                                  (uint32_t)seed ^ 0x534c4950u, (uint32_t)(seed >> 32));
+    const u32x4 r = philox4x32<kStreamRounds>(u32x4{k, j, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
+                                              (uint32_t)seed ^ 0x534c4950u, (uint32_t)(seed >> 32));
     box_muller(r.x, r.y, z[0], z[1]);
     box_muller(r.z, r.w, z[2], z[3]);
 }

@@ -614,17 +614,17 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         h->ticket_mode = true;             // p.ticket stays null in h->p: only the one-launch path selects the ticket kernel
     }
     if (rc == BN_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(BN_ERR_HIP, "hipDeviceSynchronize failed after allocation");
-    // Overlapped launches need the extra stream on ANOTHER hardware queue than the handle's stream.  HIP deals its streams onto a
-    // handful of queues in creation order, so whether a fresh stream shares the queue of the caller's stream depends on how many
-    // streams the process has created before -- a process that brought up RCCL first ran every dependent solve 5.5 us slower
-    // (15.2 instead of 9.6 us: both "streams" one queue, no overlap at all).  Ask the hardware: a kernel on the handle's stream
-    // waits (bounded) for a flag a kernel on the candidate sets; if it never sees it, the candidate is replaced by a fresh stream.
+    // Overlapped launches need an extra stream that DISPATCHES concurrently with the handle's stream.  HIP deals its streams onto a
+    // handful of hardware queues in creation order, so which queue a fresh stream lands on depends on how many streams the process
+    // has created before: a process that brought up RCCL first got the handle's own queue (15.2 instead of 9.6 us per solve: no
+    // overlap at all).  Ask the hardware (launch_queue_probe: can the candidate dispatch while a grid larger than the chip is still
+    // being placed on the handle's stream?); a candidate that fails is parked and a fresh stream takes its place.
     if (rc == BN_OK && may_overlap) {
         int *probe = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 1) * bn::kFlagStride);      // the spare counter slot
         for (int q = 0; rc == BN_OK && q + 1 < h->n_streams; ++q) {
             for (int attempt = 0; attempt < 8; ++attempt) {
                 int seen = 0;
-                if (hipMemset(probe, 0, 2 * sizeof(int)) != hipSuccess || bn::launch_queue_probe(probe, h->stream, h->xstream[q]) != hipSuccess ||
+                if (hipMemset(probe, 0, 2 * sizeof(int)) != hipSuccess || bn::launch_queue_probe(probe, h->stream, h->xstream[q], h->n_cus) != hipSuccess ||
                     hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->xstream[q]) != hipSuccess ||
                     hipMemcpy(&seen, probe + 1, sizeof seen, hipMemcpyDeviceToHost) != hipSuccess) {
                     (void)hipGetLastError();

@@ -157,9 +157,9 @@ hipError_t launch_env_step(const SolveParams &p, const float *actions, float *st
 hipError_t launch_env_collision(const SolveParams &p, const float *states, int N, float thr, const float *z, uint64_t draw,
                                 unsigned char *out, hipStream_t s);
 
-// flag_and_seen: two zeroed device ints.  A kernel on `waiter` spins (bounded) until a kernel on `setter` has set the flag and
-// records in [1] whether it saw it: only if the two streams run concurrently (different hardware queues).
-hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter);
+// flag_and_seen: two zeroed device ints.  A grid on `waiter` that the chip cannot hold at once stays until a kernel on `setter` has
+// set the flag (bounded) and records in [1] whether its first workgroup saw it: only if the two streams dispatch concurrently.
+hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter, int n_cus);
 hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipStream_t s);   // 0 sqrt, 1 sin, 2 cos, 3 wrap, 4 wrap_near
 
 // layout conversion helpers (planner-native k-fastest <-> reference k-major)

@@ -524,21 +524,31 @@ hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipSt
     return hipGetLastError();
 }
 
-// ---- do two streams run concurrently? (bn_mppi_create: the extra stream of overlapped launches must not share a hardware queue
-// with the handle's stream) ----
+// ---- can two streams DISPATCH concurrently? (bn_mppi_create: the extra stream of overlapped launches) ----
+// HIP deals its streams onto a handful of hardware queues in creation order; two streams on ONE queue serialise (seen: a process that
+// had brought up RCCL first, 15.2 instead of 9.6 us per dependent solve).  The probe asks for a little more than "not the same queue":
+// a waiter grid larger than the chip holds (one workgroup per CU through its LDS request) whose workgroups stay until a flag is set,
+// and a one-thread setter on the candidate stream.  Workgroup 0 reports whether it saw the flag before its (bounded) patience ran out:
+// only if the setter could be dispatched while the waiter grid was still being placed -- which is what an overlapped launch of more
+// workgroups than the chip holds (64 instances x 17) needs from its successor's queue.
 __global__ void queue_probe_wait_kernel(int *flag, int *seen)
 {
-    for (int it = 0; it < 4000; ++it) {                 // ~1.5 ms at most
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { *seen = 1; return; }
-        __builtin_amdgcn_s_sleep(14);
+    if (threadIdx.x != 0) return;
+    int ok = 0;
+    for (int it = 0; it < 2000 && !ok; ++it) {          // ~0.75 ms at most
+        ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) __builtin_amdgcn_s_sleep(14);
     }
-    *seen = 0;
+    if (blockIdx.x == 0) *seen = ok;
 }
 __global__ void queue_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter)
+hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter, int n_cus)
 {
-    queue_probe_wait_kernel<<<1, 1, 0, waiter>>>(flag_and_seen, flag_and_seen + 1);
+    const size_t lds = 96 * 1024;                       // one workgroup per CU
+    hipError_t e = ensure_lds(queue_probe_wait_kernel, lds);
+    if (e != hipSuccess) return e;
+    queue_probe_wait_kernel<<<dim3((unsigned)(n_cus + n_cus / 2)), dim3(64), lds, waiter>>>(flag_and_seen, flag_and_seen + 1);
     queue_probe_set_kernel<<<1, 1, 0, setter>>>(flag_and_seen);
     return hipGetLastError();
 }

@@ -42,7 +42,7 @@ typedef enum bn_status {
 
 /* Where the per-solve standard-normal noise eps comes from (mppi.py:149-151). */
 typedef enum bn_noise_kind {
-    BN_NOISE_PHILOX = 0,      /* generated in the rollout kernel (Philox4x32-10 + Box-Muller) */
+    BN_NOISE_PHILOX = 0,      /* generated in the rollout kernel (Philox4x32 + Box-Muller: eight rounds for the per-rollout streams) */
     BN_NOISE_HOST_KT2 = 1,    /* host pointer, (B,K,T,2): the reference's rsample layout       */
     BN_NOISE_DEVICE_KT2 = 2,  /* device pointer, (B,K,T,2)                                      */
     BN_NOISE_DEVICE_T2K = 3   /* device pointer, (B,T,2,K): planner-native, coalesced           */
