@@ -135,7 +135,8 @@ struct bn_mppi {
     const float *last_eps = nullptr; // noise of the latest solve (caller-owned unless BN_NOISE_HOST_KT2) and its layout
     bn::EpsMode last_mode = bn::kEpsPhilox;
     float *d_slip_std = nullptr;     // sampled-slip mode
-    float *d_ustar2[2] = {nullptr, nullptr}, *d_stats2[2] = {nullptr, nullptr};   // ticket-merge outputs by solve parity
+    float *d_ustar2[kSlots] = {}, *d_stats2[kSlots] = {};   // ticket-merge outputs, one per slot like the other per-solve buffers (overlapped: S + 1 needed)
+    bool ticket_overlap = false;     // ticket path (deterministic kernel, K > 4096): consecutive launches of a batch overlap too (round 3)
     std::vector<float> dwa_stage;    // host staging of bn_mppi_dwa_solve's upload
     int *d_ticket = nullptr;
     float *d_gpart = nullptr;
@@ -252,11 +253,11 @@ int flush_tail(bn_mppi *h, float *out_copy = nullptr)
     if (!h->tail_pending) return BN_OK;
     bn::SolveParams p = h->p;
     p.out_copy = out_copy;
-    const int cur = (int)((h->solves - 1) & 1), cur3 = (int)((h->solves - 1) % kSlots);
+    const int cur3 = (int)((h->solves - 1) % kSlots);
     p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state = h->d_state_copy[cur3];
     if (h->ticket_mode) {
         p.tail_merged = 1;
-        p.ustar_prev = h->d_ustar2[cur]; p.stats_prev = h->d_stats2[cur];
+        p.ustar_prev = h->d_ustar2[cur3]; p.stats_prev = h->d_stats2[cur3];
     }
     p.tail_solve = h->solves - 1;
     if (h->in_episode) {
@@ -572,7 +573,12 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     // the next solve takes the slot a finished one frees and waits there for ITS instance's previous solve only
     h->role_overlap = h->pipelined && !h->lat_kernel && !(cfg->flags & BN_FLAG_NO_OVERLAP);
     if (const char *e = std::getenv("BN_ROLE_OVERLAP")) h->role_overlap = h->role_overlap && e[0] != '0';   // experiments
-    const bool may_overlap = (h->lat_kernel || h->role_overlap) && !(cfg->flags & BN_FLAG_NO_OVERLAP);
+    // the deterministic kernel's ticket path (K > 4096: one launch per solve, merge by the last workgroup) overlaps its launches as well
+    const bool ticket_det = !p.slip_on && !h->pipelined && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 1024 &&
+                            bn::finish_lds_bytes(p) + 256 <= bn::rollout_lds_bytes(p);
+    h->ticket_overlap = (ticket_det || (!(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p))) && !(cfg->flags & BN_FLAG_NO_OVERLAP) &&
+                        !std::getenv("BN_NO_TICKET_OVERLAP");
+    const bool may_overlap = (h->lat_kernel || h->role_overlap || h->ticket_overlap) && !(cfg->flags & BN_FLAG_NO_OVERLAP);
     if (may_overlap) {
         // Two launches in flight.  Measured with three (role kernel, 64 instances): 23.3 instead of 22.6 us per launch; with
         // four the launches starve each other of slots (waits expire).  The slot / buffer arithmetic below holds for up to kMaxStreams.
@@ -594,7 +600,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     if (p.slip_on) {
         alloc(&h->d_slip_std, (size_t)h->n_maps * p.G * p.G * 4);
         p.slip_std = h->d_slip_std;
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kSlots; ++q) {
             alloc(&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4);
             alloc(&h->d_stats2[q], (size_t)p.B * 2 * 4);
         }
@@ -602,9 +608,9 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         alloc(&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4);
         p.ticket = h->d_ticket; p.gpart = h->d_gpart;
         h->ticket_mode = !(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p);
-    } else if (!h->pipelined && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 1024 && bn::finish_lds_bytes(p) + 256 <= bn::rollout_lds_bytes(p)) {
-        // K > 2048: too many partials for every workgroup to re-merge; the last workgroup of a launch merges them
-        for (int q = 0; q < 2; ++q) {
+    } else if (ticket_det) {
+        // K > 4096: too many partials for every workgroup to re-merge; the last workgroup of a launch merges them
+        for (int q = 0; q < kSlots; ++q) {
             alloc(&h->d_ustar2[q], (size_t)p.B * p.T * 2 * 4);
             alloc(&h->d_stats2[q], (size_t)p.B * 2 * 4);
         }
@@ -662,7 +668,9 @@ void bn_mppi_destroy(bn_mppi_t *h)
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost_out,
                     h->d_w, h->d_ustar /* d_xstar lives in the same block */, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
-                    h->d_ustar2[0], h->d_ustar2[1], h->d_stats2[0], h->d_stats2[1], h->d_ticket, h->d_gpart, h->d_mean_used};
+                    h->d_ustar2[0], h->d_ustar2[1], h->d_ustar2[2], h->d_ustar2[3], h->d_stats2[0], h->d_stats2[1], h->d_stats2[2], h->d_stats2[3],
+                    h->d_ticket, h->d_gpart, h->d_mean_used};
+    static_assert(kSlots == 4, "the list above names the four slots");
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (h->d_flags) (void)hipFree(h->d_flags);
@@ -853,7 +861,6 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     }
     h->last_eps = p.eps;
     h->last_mode = mode;
-    const int cur = (int)(h->solves & 1), prev = cur ^ 1;                         // ticket-merge outputs: by parity
     const int cur3 = (int)(h->solves % kSlots), prev3 = (int)((h->solves + kSlots - 1) % kSlots);    // per-solve buffers: kSlots slots
     p.solve = h->solves;
     p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state_copy = h->d_state_copy[cur3];
@@ -919,7 +926,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         if (p.self_tail) h->prev_published = false;                // the next solve starts from the mean that tail writes, in stream order
         return BN_OK;
     }
-    h->prev_published = false;
+    if (!(h->ticket_overlap && overlap && !shard_rollout)) h->prev_published = false;
     p.have_prev = 0;
     p.mean_from_part = 0;
     p.tail_solve = p.solve;
@@ -929,11 +936,32 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         p.have_prev = h->tail_pending ? 1 : 0;
         p.tail_merged = 1;
         p.tail_solve = p.solve - 1;
-        p.ustar_cur = h->d_ustar2[cur]; p.stats_cur = h->d_stats2[cur];
-        p.ustar_prev = h->d_ustar2[prev]; p.stats_prev = h->d_stats2[prev];
+        p.ustar_cur = h->d_ustar2[cur3]; p.stats_cur = h->d_stats2[cur3];
+        p.ustar_prev = h->d_ustar2[prev3]; p.stats_prev = h->d_stats2[prev3];
         p.ticket = h->d_ticket;
-        if (p.slip_on) BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
-        else BN_HIP(bn::launch_rollout(p, mode, h->stream));
+        hipStream_t st = h->stream;
+        p.flag_tail = h->d_flags + kSlots * B * bn::kFlagStride;
+        if (p.have_prev) { p.wait_tail = h->tails; h->tails += 1; }
+        if (h->ticket_overlap && overlap) {
+            // member of an overlapped batch (as in the pipelined branch above): the merge of this launch counts itself into its slot
+            // (one count per solve), the next launch -- rollouts and tail -- waits for that count instead of for this kernel's end
+            p.flag_part = h->d_flags;
+            p.err = h->d_err;
+            if (h->arm_snap) { p.mean_snap = h->d_mean_snap; h->arm_snap = false; }
+            p.cur_slot = cur3; p.prev_slot = prev3;
+            p.wait_part = h->pub[prev3];
+            if (alt_buffers) {
+                if (h->d_Xalt[alt_buffers - 1]) p.X = h->d_Xalt[alt_buffers - 1];
+                if (h->d_Ualt[alt_buffers - 1] && p.U) p.U = h->d_Ualt[alt_buffers - 1];
+            }
+            p.overlap = (h->prev_published && p.have_prev) ? 1 : 0;
+            if (on_stream) st = on_stream;
+            if (p.overlap) h->overlap_used = true;
+            h->pub[cur3] += 1;                                         // one count per instance and solve
+            h->prev_published = true;
+        }
+        if (p.slip_on) BN_HIP(bn::launch_rollout_sampled(p, mode, st));
+        else BN_HIP(bn::launch_rollout(p, mode, st));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
         h->tail_pending = true;
@@ -1052,7 +1080,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // the tails (aux workgroups) are ordered by a second counter.  Results are bit-identical to the one-stream chain.
     // Device-side episodes overlap the same way (role kernel): the successor reads the state its predecessor advanced with
     // device-scope loads after its wait (64 instances: 29.6 -> 24.8 us per control step).
-    const bool overlap = (h->lat_kernel || h->role_overlap) && h->n_streams > 1 && (h->d_Xalt[0] || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE &&
+    const bool overlap = (h->lat_kernel || h->role_overlap || h->ticket_overlap) && h->n_streams > 1 && (h->d_Xalt[0] || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE &&
                          noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending && !h->overlap_off;
     bool mine = overlap;
     if (overlap) {                                      // see g_overlap_owner

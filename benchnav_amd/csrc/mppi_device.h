@@ -793,13 +793,13 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     float m, S;
     if (p.tail_merged) {
         for (int j = tid; j < 2 * T; j += NT) {
-            const float u = p.ustar_prev[(size_t)b * 2 * T + j];
+            const float u = ld<AGENT>(p.ustar_prev + (size_t)b * 2 * T + j);
             us[j] = u;
             st<AGENT>(p.ustar + (size_t)b * 2 * T + j, u);
             if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, u);
         }
-        m = p.stats_prev[b * 2 + 0];
-        S = p.stats_prev[b * 2 + 1];
+        m = ld<AGENT>(p.stats_prev + b * 2 + 0);
+        S = ld<AGENT>(p.stats_prev + b * 2 + 1);
         __syncthreads();
     } else {
         merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, int bl
         if (tid == 0) *flag = (atomicAdd(ticket + 1 + g, 1) == in_group - 1) ? 1 : 0;
         __syncthreads();
         if (!*flag) return;
-        if (tid == 0) ticket[1 + g] = 0;
+        if (tid == 0) __hip_atomic_store(ticket + 1 + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an overlapped successor takes its tickets behind the count below)
         float *grow = p.gpart + ((size_t)b * 64 + g) * PS;
         merge_group<true, true>(part, g * kGroupRows, in_group, T, tid & 63, tid >> 6, NT / 64, grow);
         rows = p.gpart + (size_t)b * 64 * PS;
@@ -1013,15 +1013,29 @@ __device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, int bl
     __syncthreads();
     if (!*flag) return;
     BN_STAMP_ANY(6);
-    if (tid == 0) ticket[0] = 0;                       // ready for the next launch (ordered by the stream)
+    if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (ordered by the stream, or by the count below)
     float m, S;
     merge_partials<NT, true, false>(rows, nrows, T, us, sc, red, tid, m, S, false, MergeLoads{});
+    // Member of an overlapped batch (p.flag_part): the next launch may be running already -- on the other stream, its workgroups
+    // waiting for exactly this -- so what it reads goes out as device-scope stores and the merge counts itself in behind them.
+    const bool pubm = p.flag_part != nullptr;
     for (int j = tid; j < 2 * T; j += NT) {
-        p.ustar_cur[(size_t)b * 2 * T + j] = us[j];
-        if (p.mean_used) p.mean_used[(size_t)b * 2 * T + j] = p.mean[(size_t)b * 2 * T + j];   // what this solve sampled around
-        p.mean[(size_t)b * 2 * T + j] = us[j];         // _previous_action_seq = U*, no shift (mppi.py:217)
+        const size_t at = (size_t)b * 2 * T + j;
+        if (pubm) {
+            store_agent(p.ustar_cur + at, us[j]);
+            if (p.mean_used) store_agent(p.mean_used + at, load_agent(p.mean + at));
+            store_agent(p.mean + at, us[j]);
+        } else {
+            p.ustar_cur[at] = us[j];
+            if (p.mean_used) p.mean_used[at] = p.mean[at];   // what this solve sampled around
+            p.mean[at] = us[j];                        // _previous_action_seq = U*, no shift (mppi.py:217)
+        }
     }
-    if (tid == 0) { p.stats_cur[b * 2 + 0] = m; p.stats_cur[b * 2 + 1] = S; }
+    if (tid == 0) {
+        if (pubm) { store_agent(p.stats_cur + b * 2 + 0, m); store_agent(p.stats_cur + b * 2 + 1, S); }
+        else { p.stats_cur[b * 2 + 0] = m; p.stats_cur[b * 2 + 1] = S; }
+    }
+    if (pubm) publish_counter(flag_ctr(p.flag_part, p.cur_slot * p.B + b), tid);
     BN_STAMP_ANY(7);
 }
 

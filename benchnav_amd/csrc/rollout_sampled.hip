@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, b = wg.b;
     if (wg.aux) {
         // aux workgroup: weights, cost copy and X* of the previous solve (merged by its own last workgroup)
-        finish_body<GEO, true, kSampledThreads>(p, b, nullptr, p.cost_prev, p.state_prev, smem);
+        if (p.overlap) finish_body<GEO, true, kSampledThreads, false, true>(p, b, nullptr, p.cost_prev, p.state_prev, smem);
+        else finish_body<GEO, true, kSampledThreads>(p, b, nullptr, p.cost_prev, p.state_prev, smem);
         return;
     }
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,21 +70,25 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
         win2[e] = make_float2(mu[g], sg[g]);
     }
+    // Overlapped launch on the ticket path (round 3): the previous solve may still be running on the other stream; its last workgroup
+    // merges the partials and counts that in.  The window and the slip draws do not need the mean: they go first, the wait sits
+    // between them and the controls.
+    const bool ovs = p.overlap != 0;
+    const bool tpub = p.flag_part != nullptr;          // member of an overlapped batch: costs and start state as device-scope stores
+    if (!ovs)
     for (int j = tid; j < 2 * T; j += kSampledThreads) {
         const float m = p.mean[(size_t)b * 2 * T + j];
         ml[j] = m;
         mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
     }
-    if (wg.blk == 0 && tid < 3) p.state_copy[b * 3 + tid] = p.state[b * 3 + tid];
+    if (wg.blk == 0 && tid < 3) { if (tpub) store_agent(p.state_copy + b * 3 + tid, p.state[b * 3 + tid]); else p.state_copy[b * 3 + tid] = p.state[b * 3 + tid]; }
     __syncthreads();
 
-    // ---- phase 1: controls and slip draws of every step ----
+    // ---- phase 1: slip draws, then controls, of every step ----
     {
         const int nE = (T + 1) >> 1, nS = TP >> 1;
-        for (int q = wid; q < nE + nS; q += kSampledWaves) {
-            if (q < nE) {
-                produce_pair<EPS, STORE_U>(p, p.eps, b, kk, 2 * q, p.solve, ml, Ul, Ub, Kp, lane);
-            } else {
+        for (int q = nE + wid; q < nE + nS; q += kSampledWaves) {
+            {
                 const int r0 = 2 * (q - nE), r1 = r0 + 1;
                 float z[4];
                 if (p.zt) {
@@ -98,6 +103,18 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
                 Zc[r0 * 64 + lane] = z[2]; Zc[r1 * 64 + lane] = z[3];
             }
         }
+        if (ovs) {
+            if (tid == 0) wait_counter<16>(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p.err);
+            __syncthreads();
+            for (int j = tid; j < 2 * T; j += kSampledThreads) {
+                const float m = load_agent(p.mean + (size_t)b * 2 * T + j);
+                ml[j] = m;
+                mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
+            }
+            __syncthreads();
+        }
+        if (p.mean_snap && wg.blk == 0 && wid == 0) snapshot_mean(p, b, ml, lane);
+        for (int q = wid; q < nE; q += kSampledWaves) produce_pair<EPS, STORE_U>(p, p.eps, b, kk, 2 * q, p.solve, ml, Ul, Ub, Kp, lane);
     }
     __syncthreads();
     BN_STAMP(1);
@@ -160,7 +177,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
 #pragma unroll 16
         for (int t = 0; t < T; ++t) Sd += (double)Zc[t * 64 + lane];          // reads batched: one LDS round trip per 16 steps
         const float cost = ((float)Sd + Zc[T * 64 + lane]) + ad[lane];                 // mppi.py:184-190
-        if (active) p.cost[(size_t)b * K + k] = cost;
+        if (active) { if (tpub) store_agent(p.cost + (size_t)b * K + k, cost); else p.cost[(size_t)b * K + k] = cost; }
         const float zz = active ? (-cost) / p.lambda_ : -INFINITY;
         const float zmax = wave_max(zz);
         const float e = active ? expf(zz - zmax) : 0.0f;

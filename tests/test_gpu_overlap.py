@@ -30,8 +30,11 @@ def _outputs(pl, B, T):
 
 @pytest.mark.parametrize("K,T,B,noise,lean,n", [(1024, 50, 1, "philox", False, 40), (1024, 50, 3, "philox", True, 25), (1000, 33, 2, "kt2", False, 12),
                                                 (2048, 50, 1, "t2k", False, 9), (130, 7, 5, "philox", False, 60), (64, 1, 1, "philox", False, 30),
-                                                (1024, 50, 1, "philox", False, 3)],
-                         ids=["c2", "c2-B3-lean", "ragged-kt2", "K2048-t2k", "small-B5", "T1", "n3"])
+                                                (1024, 50, 1, "philox", False, 3),
+                                                # the ticket path (K > 4096: merge by the last workgroup, counted in for the overlapped successor)
+                                                (5000, 50, 1, "philox", False, 12), (16384, 100, 1, "philox", False, 7), (8192, 33, 2, "kt2", True, 9),
+                                                (4160, 20, 3, "t2k", False, 16)],
+                         ids=["c2", "c2-B3-lean", "ragged-kt2", "K2048-t2k", "small-B5", "T1", "n3", "ticket-ref5000", "ticket-c5", "ticket-B2-lean", "ticket-B3-n16"])
 def test_overlapped_chain_equals_one_stream_chain(K, T, B, noise, lean, n):
     import torch
     from benchnav_amd import _capi, synth
@@ -309,3 +312,23 @@ def test_mixed_call_sequences_and_a_long_chain():
             res[overlap] = seq
     for j, (a_, b_) in enumerate(zip(res[True], res[False])):
         assert np.array_equal(a_, b_), j
+
+
+def test_sampled_slip_launches_overlap_bit_identically():
+    """BASELINE config 3's kernel on the ticket path: overlapped launches (slip draws before the wait for the predecessor's merged
+    mean, controls behind it) give the chain of the one-stream launches, bit for bit."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    K, T = 8192, 50
+    inst = synth.make_instance(G, seed=5)
+    st = inst.start.cuda()
+    res = {}
+    for overlap in (False, True):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, sampled_slip=True, seed=9, overlap=overlap) as pl:
+            pl.set_map(inst.risk.numpy()); pl.set_slip_std(synth.slip_std_map(G, seed=5).numpy()); pl.set_goal(inst.goal.numpy())
+            pl.solve_n_async_device(9, st.data_ptr())
+            pl.sync()
+            res[overlap] = (pl.states(), pl.costs(), pl.weights(), pl.get_mean())
+            assert pl.solve_count() == 9
+    for a_, b_ in zip(res[True], res[False]):
+        assert np.array_equal(a_, b_)
