@@ -4,6 +4,9 @@ import os, sys, time, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from benchnav_amd import build as _b
+if os.environ.get("BN_TOOL_LIB", "main") != "main":                     # a variant built by tools/build_variant_fast.py <name>
+    _b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ["BN_TOOL_LIB"])
 from benchnav_amd import NativeMPPI, synth
 torch.set_num_threads(1)
 inst = synth.make_instance(256, seed=0)
