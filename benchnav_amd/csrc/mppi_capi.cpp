@@ -456,6 +456,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.x0 = cfg->x_limits[0]; p.y0 = cfg->y_limits[0];
     p.x_hi = cfg->x_limits[1]; p.y_hi = cfg->y_limits[1];
     p.dt = cfg->dt; p.thr = cfg->stuck_threshold; p.lambda_ = cfg->lambda_;
+    {
+        int e = 0;
+        const float m = std::frexp(cfg->lambda_, &e);                  // lambda_ = m * 2^e, m in [0.5, 1)
+        p.inv_lambda = (m == 0.5f && e > -120 && e < 120) ? std::ldexp(1.0f, 1 - e) : 0.0f;
+    }
     p.sigma0 = cfg->sigma[0]; p.sigma1 = cfg->sigma[1];
     p.iv0 = cfg->inv_var[0]; p.iv1 = cfg->inv_var[1];
     p.umin0 = cfg->u_min[0]; p.umax0 = cfg->u_max[0];

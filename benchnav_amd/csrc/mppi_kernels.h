@@ -42,6 +42,7 @@ struct SolveParams {
     float x0, y0;        // index origin == lower clamp (reference grid_map.py:199-201, robot_model.py:93-94)
     float x_hi, y_hi;    // upper clamp
     float dt, thr, lambda_;
+    float inv_lambda;           // 1 / lambda_ when that is exact (lambda_ a power of two, reciprocal a normal number), else 0: x / lambda_ == x * inv_lambda bit for bit
     float sigma0, sigma1, iv0, iv1;
     float umin0, umax0, umin1, umax1;
     uint64_t seed;
