@@ -30,6 +30,7 @@ for c in B1 B64; do
 done
 cd $REPO
 python tools/traffic_from_pmc.py $OUT/pmc $TAG $COMMIT
+cp $OUT/pmc/traffic.json profiles/traffic.json      # the bench lines below carry this pass's traffic figures
 timeout 600 python bench.py --steps 3000 --warmup 200 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_args.json 2>> $OUT/bench.err
 tail -c 400 $OUT/${TAG}_bench.json
