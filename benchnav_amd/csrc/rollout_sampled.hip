@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         const float2 ms = win2[__float_as_int(o.w)];
         const float tc = trav_from_slip(ms.x, ms.y, Zc[t * 64 + lane]);                // objectives.py:50
         const float dx = o.x - gx, dy = o.y - gy;
-        Zc[t * 64 + lane] = sqrt_cr(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f);  // objectives.py:46-53
+        Zc[t * 64 + lane] = sqrt_cr_normal(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f);  // objectives.py:46-53
     }
     __syncthreads();
     BN_STAMP(3);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         const int ec = slip_cell_safe<GEO, false>(p, w, xn, yn);
         const float tc = trav_from_slip(mu[ec], sg[ec], zq[2 + (t & 1)]);
         const float dx = xn - gx, dy = yn - gy;
-        Sd += (double)(sqrt_cr(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f));
+        Sd += (double)(sqrt_cr_normal(dx * dx + dy * dy) + (tc <= p.thr ? 1.0e4f : 0.0f));
         Ad += (double)(p.lambda_ * (mv[2 * t] * u0 + mv[2 * t + 1] * u1));
     }
     {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
     const int eT = slip_cell_safe<GEO, false>(p, w, x, y);
     const float tT = trav_from_slip(mu[eT], sg[eT], zq[2 + (T & 1)]);
     const float dxT = x - gx, dyT = y - gy;
-    const float term = sqrt_cr(dxT * dxT + dyT * dyT) + (tT <= p.thr ? 1.0e4f : 0.0f);
+    const float term = sqrt_cr_normal(dxT * dxT + dyT * dyT) + (tT <= p.thr ? 1.0e4f : 0.0f);
     const float cost = ((float)Sd + term) + (float)Ad;
     if (active) p.cost[(size_t)b * K + k] = cost;
     const float zz = active ? (-cost) / p.lambda_ : -INFINITY;

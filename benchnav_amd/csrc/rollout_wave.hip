@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
             Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;                                                             \
         }                                                                                                         \
         const float dx = xn - gx, dy = yn - gy;                                                                   \
-        Sd += (double)(sqrt_cr(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));   /* objectives.py:47-53 */  \
+        Sd += (double)(sqrt_cr_normal(dx * dx + dy * dy) + (c.trav <= p.thr ? 1.0e4f : 0.0f));   /* objectives.py:47-53 */  \
         Ad += (double)(p.lambda_ * (mv[2 * (t)] * (u0) + mv[2 * (t) + 1] * (u1)));      /* mppi.py:178-182 */      \
     } while (0)
     for (int t = 0; t < T; t += 2) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void rollout_wave_kernel(const SolveParams p)
         Xt[0] = c.x; Xt[Kp] = c.y; Xt[2 * Kp] = c.th;
     }
     const float dxT = c.x - gx, dyT = c.y - gy;
-    const float term = sqrt_cr(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);      // mppi.py:184
+    const float term = sqrt_cr_normal(dxT * dxT + dyT * dyT) + (c.trav <= p.thr ? 1.0e4f : 0.0f);      // mppi.py:184
     const float cost = ((float)Sd + term) + (float)Ad;                                          // mppi.py:186-190
     if (active) { if (pub) store_agent(p.cost + (size_t)b * K + k, cost); else p.cost[(size_t)b * K + k] = cost; }
     const float z = active ? (-cost) / p.lambda_ : -INFINITY;

@@ -1,5 +1,6 @@
 """Dependent solves per second of the big single-instance configurations (K=16384 T=100 G=512; sampled slip K=8192) and the
-64-instance batch, for build variants (tools/build_variant.py):  python tools/config_rate.py <variant|main> ..."""
+64-instance batch, for build variants (tools/build_variant.py):  python tools/config_rate.py <variant|main>
+(ONE library per process: two images of the library in one process contend for the per-device lock and the second one measures slow)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,4 +37,8 @@ for name in sys.argv[1:]:
     with NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, num_instances=B, shared_map=True) as pl:
         pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
         out.append(f"B=64 {rate(pl, torch.stack([inst.start] * B).cuda(), 300):6.2f} us")
+    for B, lean in ((64, True), (256, False), (256, True)):
+        with NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, num_instances=B, shared_map=True, lean=lean) as pl:
+            pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+            out.append(f"B={B}{' lean' if lean else ''} {rate(pl, torch.stack([inst.start] * B).cuda(), 300):6.2f} us")
     print(f"{name:10s} " + " | ".join(out), flush=True)
