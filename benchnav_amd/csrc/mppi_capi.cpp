@@ -482,7 +482,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     const double vmax = std::max(std::fabs((double)cfg->u_min[0]), std::fabs((double)cfg->u_max[0]));
     const double reach_cells = std::ceil((double)p.T * vmax * (double)cfg->dt / (double)cfg->resolution) + 1.0;
     p.reach = (int)std::min(reach_cells, (double)p.G);
-    p.WN = std::min(p.G, 2 * p.reach + 1);
+    // reach either side of the start cell (reach has a cell to spare), up to the whole map plus the guard row / column at index G
+    // (window_origin_wide).  An odd pitch on purpose: with 2 reach + 2 vertically adjacent cells collided in the LDS banks more
+    // often (K=16384 T=100: 27.4 -> 28.5 us per solve).
+    p.WN = std::min(p.G + 1, 2 * p.reach + 1);
     const size_t lds_budget = 160 * 1024;
     if ((cfg->flags & BN_FLAG_NO_LDS_WINDOW) || bn::rollout_lds_bytes(p) > lds_budget) p.WN = 0;
     if (bn::rollout_lds_bytes(p) > lds_budget) {
@@ -1198,7 +1201,7 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
     if (h->lat_kernel && h->d_gran[0] && !std::getenv("BN_NO_SPEC_WINDOW")) {
         const double vmax = std::max(std::fabs((double)h->p.umin0), std::fabs((double)h->p.umax0));
         const double cells = std::floor(vmax * (double)delta_t / (double)h->p.res) + 1.0;
-        if (cells <= 8.0 && h->p.WN + 2 * (int)cells <= h->p.G) {
+        if (cells <= 8.0 && h->p.WN + 2 * (int)cells <= h->p.G + 1) {
             h->p.spec_extra = (int)cells;
             if (bn::lat_lds_bytes(h->p) == 0) h->p.spec_extra = 0;      // would not fit the LDS
         }

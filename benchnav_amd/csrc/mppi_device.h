@@ -71,7 +71,7 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 //   kGeoPow2Origin0  additionally origin == 0, so the subtraction is the identity
 enum Geo : int { kGeoGeneral = 0, kGeoPow2 = 1, kGeoPow2Origin0 = 2 };
 
-struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; };   // window origin (cells), as floats, edge, edge-1
+struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; int wn; };   // window origin (cells), as floats, edge, edge-1, edge
 
 // Which workgroup of which instance this is (see rollout_grid): rollout workgroup `blk` of instance `b`, or the aux
 // workgroup of instance `b` (tail of the previous solve).  Rows past the instances hold the aux workgroups, so they are
@@ -107,16 +107,18 @@ __device__ __forceinline__ int raw_cell(float v, float origin, float res, float 
     return (int)floorf(q);                    // v_cvt_i32_f32 saturates
 }
 
-// Window of edge wn covering `reach` cells either side of the cell of (sx, sy), shifted into the map.
+// Window of edge wn covering `reach` cells either side of the cell of (sx, sy) and one more above, shifted into the map PLUS ONE
+// GUARD ROW / COLUMN at index G (staged as a copy of row / column G-1): a position on the upper map limit has the raw cell G, and
+// the reference's index clamp (grid_map.py:209) is then built into the window instead of costing the chain two clamps a step.
 template <int GEO>
 __device__ __forceinline__ Win window_origin_wide(const SolveParams &p, float sx, float sy, int reach, int wn)
 {
     const int cx = clampi(raw_cell<GEO>(sx, p.x0, p.res, p.inv_res), 0, p.G - 1);
     const int cy = clampi(raw_cell<GEO>(sy, p.y0, p.res, p.inv_res), 0, p.G - 1);
     Win w;
-    w.wx0 = min(max(cx - reach, 0), p.G - wn);
-    w.wy0 = min(max(cy - reach, 0), p.G - wn);
-    w.fx0 = (float)w.wx0; w.fy0 = (float)w.wy0; w.fwn = (float)wn; w.fwm1 = (float)(wn - 1);
+    w.wx0 = min(max(cx - reach, 0), p.G + 1 - wn);
+    w.wy0 = min(max(cy - reach, 0), p.G + 1 - wn);
+    w.fx0 = (float)w.wx0; w.fy0 = (float)w.wy0; w.fwn = (float)wn; w.fwm1 = (float)(wn - 1); w.wn = wn;
     return w;
 }
 
@@ -136,7 +138,7 @@ __device__ __forceinline__ void stage_window(float *win, const float *__restrict
     for (int e = tid; e < n; e += nthreads) {
         const int r = e / WN;
         const int c = e - r * WN;
-        const float risk = map[(size_t)(w.wy0 + r) * G + (w.wx0 + c)];
+        const float risk = map[(size_t)min(w.wy0 + r, G - 1) * G + min(w.wx0 + c, G - 1)];      // (the guard row / column: index G -> G-1)
         win[e] = 1.0f - clampf(risk, 0.0f, 1.0f);
     }
 }
@@ -162,11 +164,13 @@ __device__ __forceinline__ float trav_lookup(const SolveParams &p, const float *
     return 1.0f - clampf(map[(size_t)iy * p.G + ix], 0.0f, 1.0f);
 }
 
-// In-loop gather: (x, y) already lies inside the map limits.  The window-relative cell is computed in
-// the float domain: q = (x - origin)/res as the reference rounds it, then q - wx0 (exact: an integer
-// no larger than q is subtracted), floor, clamp to the window, row * WN + col (exact small integers),
-// one conversion.  Same cell as trav_lookup<..., false> for every in-limits position.
-template <int GEO>
+// In-loop gather: (x, y) already lies inside the map limits and within `reach` cells of the start, so its raw cell lies inside
+// the window (guard row / column included: window_origin_wide) and nothing has to be clamped.  q = (x - origin)/res as the
+// reference rounds it, then q - wx0 (exact: an integer no larger than q is subtracted), floor, row * WN + col in the float domain
+// (exact small integers), one conversion.  Same cell as trav_lookup<..., false> for every such position; six instructions before
+// the ds_read where floor, clamp, floor, clamp, fma, convert, shift-add were eight -- on the chain wave they sit on the solve's
+// critical path T times.
+template <int GEO, int ASMIDX = 0>
 __device__ __forceinline__ float trav_window(const SolveParams &p, const float *win, const Win w, float x, float y)
 {
     v2f q;
@@ -178,9 +182,17 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
     } else {
         q = v2f{(x - p.x0) / p.res, (y - p.y0) / p.res} + nw;
     }
-    const float li = clampf(floorf(q.x), 0.0f, w.fwm1);
-    const float lj = clampf(floorf(q.y), 0.0f, w.fwm1);
-    return win[(int)__builtin_fmaf(lj, w.fwn, li)];
+    if (ASMIDX == 1) {
+        // The latency kernel's chain wave: floor-and-convert in one instruction, row * WN + col as one v_mad_u32_u24 (left to itself
+        // the compiler spreads the *4 of the byte address over both terms).  Same integers.  8.65 -> 8.57 us per dependent solve;
+        // NOT for the role kernel (64 instances: +3 %): the compiler pads both ends of an asm block with a wait state and cannot
+        // schedule across it.
+        int cell, lj;
+        asm("v_cvt_flr_i32_f32 %0, %2\n\tv_cvt_flr_i32_f32 %1, %3\n\tv_mad_u32_u24 %0, %1, %4, %0"
+            : "=&v"(cell), "=&v"(lj) : "v"(q.x), "v"(q.y), "s"(w.wn));
+        return win[cell];
+    }
+    return win[(int)__builtin_fmaf(floorf(q.y), w.fwn, floorf(q.x))];
 }
 
 // Per-rollout recurrence state: the clamped/wrapped state t, its traversability, sin/cos of its heading.
@@ -216,7 +228,7 @@ __device__ __forceinline__ void chain_prepare(const SolveParams &p, Chain &c, fl
 
 // PREP: the caller's loop hands over the NEXT step's controls (u0n, u1n) and chain_prepare runs for them at the end of this step,
 // under the gather's latency (the role kernels' chain wave); otherwise the step prepares itself from its own controls first.
-template <int GEO, bool LDSWIN, bool FIRST, bool THETA = true, bool PREP = false>
+template <int GEO, bool LDSWIN, bool FIRST, bool THETA = true, bool PREP = false, int ASMIDX = 0>
 __device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
                                            const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn,
                                            float u0n = 0.0f, float u1n = 0.0f)
@@ -232,7 +244,7 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
     c.y = clampf(yn, p.y0, p.y_hi);                                    // :94
     if (BN_ABLATE & 32) { c.trav = 0.5f + 0.001f * c.x; } else
-    c.trav = LDSWIN ? trav_window<GEO>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
+    c.trav = LDSWIN ? trav_window<GEO, ASMIDX>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
     __builtin_amdgcn_sched_barrier(0);
     if (THETA) tn = theta_step(c.th, dth, FIRST); else tn = dth;
     if (BN_ABLATE & 16) { c.sn = c.sn * 0.5f + dth; c.cs = 1.0f - c.sn; } else
@@ -857,7 +869,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             w = window_origin<GEO>(p, sx, sy);
             for (int e = tid; e < p.WN * p.WN; e += NT) {
                 const int r = e / p.WN, c = e - r * p.WN;
-                const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
+                const size_t g = (size_t)min(w.wy0 + r, p.G - 1) * p.G + min(w.wx0 + c, p.G - 1);
                 win2[e] = make_float2(map[g], sg[g]);
             }
         }

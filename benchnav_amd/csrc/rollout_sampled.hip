@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
     // ---- phase 0: window of (mean, std) pairs, warm-start mean ----
     for (int e = tid; e < WN2; e += kSampledThreads) {
         const int r = e / p.WN, c = e - r * p.WN;
-        const size_t g = (size_t)(w.wy0 + r) * p.G + (w.wx0 + c);
+        const size_t g = (size_t)min(w.wy0 + r, p.G - 1) * p.G + min(w.wx0 + c, p.G - 1);      // (guard row / column: window_origin_wide)
         win2[e] = make_float2(mu[g], sg[g]);
     }
     // Overlapped launch on the ticket path (round 3): the previous solve may still be running on the other stream; its last workgroup
