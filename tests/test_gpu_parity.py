@@ -150,6 +150,31 @@ def test_shifted_origin_geometry_against_oracle(res, x_lim, y_lim):
             assert_oracle_parity(oracle_metrics(native_outputs(pl, us, xs), orc), ctx=f"res={res} lds={lds}")
 
 
+@pytest.mark.parametrize("kernel", ["lat", "role", "wave"])
+def test_rollouts_pinned_to_the_upper_map_limits(kernel):
+    """A position ON the upper limit has the raw cell G; the reference clamps the index to G-1 (grid_map.py:209).  The kernels'
+    reachable window carries a guard row / column for that cell instead of clamping in the chain: start next to
+    the upper-right corner, heading out, so that most rollouts spend most steps on x_hi and / or y_hi."""
+    O = _oracle()
+    from benchnav_amd import NativeMPPI
+    K, T, G, res = 256, 30, 64, 0.5
+    rng = np.random.default_rng(23)
+    R = (rng.random((G, G)) * 0.8).astype(np.float32)
+    hi = G * res
+    state = np.array([hi - 0.3, hi - 0.2, 0.7], np.float32)
+    goal = np.array([hi + 3.0, hi + 3.0], np.float32)
+    mean = np.tile(np.array([0.9, 0.0], np.float32), (T, 1))
+    eps = rng.standard_normal((K, T, 2)).astype(np.float32)
+    p = O.make_params(K, T, G, res, goal, trig=O.TRIG_SPEC)
+    orc = O.solve(p, R, state, mean, eps)
+    X = np.asarray(orc["X"])
+    assert (X[..., 0] >= hi).mean() > 0.2 and (X[..., 1] >= hi).mean() > 0.2, "the case does not reach the limits"
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=res, store_controls=True, kernel=kernel) as pl:
+        pl.set_map(R); pl.set_goal(goal); pl.set_mean(mean)
+        us, xs = pl.solve(state, eps)
+        assert_oracle_parity(oracle_metrics(native_outputs(pl, us, xs), orc), ctx=f"kernel={kernel}")
+
+
 def test_solve_n_async_equals_a_python_loop():
     import torch
     from benchnav_amd import _capi
