@@ -181,3 +181,11 @@ def solve_sampled(p: OracleParams, MU, SG, state, mean, eps, zt, zc, zo):
     lib().oracle_solve_sampled(C.byref(p), _fp(MU), _fp(SG), _fp(state), _fp(mean), _fp(eps), _fp(zt), _fp(zc), _fp(zo),
                                _fp(out["U"]), _fp(out["X"]), _fp(out["cost"]), _fp(out["w"]), _fp(out["Ustar"]), _fp(out["Xstar"]))
     return out
+
+
+def portable_normal(seed: int, stream: int, n: int):
+    """n standard normals of stream `stream` under `seed`: identical bits on every host (oracle_portable_normal).
+    Test-input generator for the census fixtures; not part of the parity spec."""
+    out = np.empty(int(n), np.float32)
+    lib().oracle_portable_normal(C.c_uint64(seed), C.c_uint64(stream), C.c_int64(n), _fp(out))
+    return out

@@ -581,10 +581,132 @@ def run_boundary_case():
           f"{os.path.getsize(p_)/1024:.0f} KiB + boundary.json")
 
 
+# ---- parity census (round 4): the reference at BASELINE sizes, on a noise stream every host can regenerate ----------------------
+class _PortableNoise:
+    """Replaces torch.distributions' _standard_normal (what MultivariateNormal.rsample draws its eps from, mppi.py:105-107,
+    149-151) by the oracle's portable stream: stream 0 is the constructor's discarded draw, stream i + 1 the eps of solve i.
+    The reference's own arithmetic on that eps (loc + scale_tril @ eps, clamp, ...) is untouched."""
+
+    def __init__(self, seed):
+        import torch.distributions.multivariate_normal as mvn
+        self.seed, self.stream, self._mvn, self._real = int(seed), 0, mvn, mvn._standard_normal
+
+    def __enter__(self):
+        from oracle import oracle as O
+
+        def portable(shape, dtype, device):
+            n = int(np.prod(tuple(shape)))
+            eps = torch.from_numpy(O.portable_normal(self.seed, self.stream, n)).reshape(tuple(shape)).to(dtype)
+            self.stream += 1
+            return eps
+        self._mvn._standard_normal = portable
+        return self
+
+    def __exit__(self, *exc):
+        self._mvn._standard_normal = self._real
+
+
+def _cell(v, origin, res, G):
+    """grid_map.py:195-209 for a float32 array."""
+    q = np.floor((v.astype(np.float32) - np.float32(origin)) / np.float32(res))
+    return np.clip(q, 0, G - 1).astype(np.int64)
+
+
+def census_solve(fx_static, R, state, mean, eps, X_ref, modes=(0, 1, 2)):
+    """Per oracle mode: max |dX| per rollout over ALL slots against the reference's full batch."""
+    from oracle import oracle as O
+    out = {}
+    for trig in modes:
+        p = O.make_params(fx_static["K"], fx_static["T"], fx_static["G"], fx_static["res"], fx_static["goal"], thr=fx_static["thr"],
+                          lambda_=fx_static["lam"], sigma=fx_static["sigmas"], trig=trig)
+        got = O.solve(p, R, state, mean, eps)
+        out[trig] = np.abs(got["X"] - X_ref).reshape(X_ref.shape[0], -1).max(1)
+    return out
+
+
+def run_census_case(name, *, G, K, T, maps, n_solves, res=0.5, thr=0.3, lam=0.5, sigmas=(0.5, 0.5), seed=42, store=True, event_bar=2e-5):
+    """The reference's MPPI.forward at a BASELINE size over several maps and warm-started solves, on the portable noise stream.
+    Stored per solve: state, mean, U*, X*, w, cost and slots T//2 and T of every rollout; for every rollout whose trajectory
+    leaves `event_bar` against ANY of the oracle's arithmetic modes (a cell flip) the reference's full row.
+    Returns the census counts (rollouts over 1e-4 per mode, max deviation per mode) so that main() can print / record them."""
+    from oracle import oracle as O
+    out = dict(G=G, res=res, K=K, T=T, thr=thr, lam=lam, seed=seed, sigmas=np.asarray(sigmas, np.float32), n_maps=len(maps), n_solves=n_solves,
+               slots=np.asarray([T // 2, T], np.int32), torch_version=torch.__version__, event_bar=event_bar)
+    counts = {m: 0 for m in (0, 1, 2)}
+    worst = {m: 0.0 for m in (0, 1, 2)}
+    total = 0
+    for mi, (kind, mseed) in enumerate(maps):
+        inst = make_instance(G, seed=mseed, resolution=res, kind=kind)
+        torch.manual_seed(1234)
+        gm, dyn, obj = build_reference(G, res, inst.risk, torch.full((G, G), 0.1), "expected_value", None, inst.goal, thr)
+        R = dyn._traversability_model._risks.clone().numpy()
+        fx_static = dict(G=G, K=K, T=T, res=res, goal=inst.goal.numpy(), thr=thr, lam=lam, sigmas=list(sigmas))
+        with _PortableNoise(seed + 1000 * mi) as pn:
+            solver = MPPI(horizon=T, num_samples=K, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, sigmas=torch.tensor(sigmas),
+                          lambda_=lam, device=torch.device("cpu"), seed=seed)
+            state = inst.start.clone()
+            out[f"R_{mi}"] = R
+            out[f"goal_{mi}"] = inst.goal.numpy().astype(np.float32)
+            out[f"map_{mi}"] = f"{kind}:{mseed}"
+            out[f"noise_seed_{mi}"] = seed + 1000 * mi
+            for i in range(n_solves):
+                mean = solver._previous_action_seq.clone()
+                with torch.no_grad():
+                    U_opt, X_opt = solver(state)
+                eps = (solver._action_noises / torch.tensor(sigmas)).numpy()
+                assert np.array_equal(eps, O.portable_normal(pn.seed, i + 1, K * T * 2).reshape(K, T, 2)), "portable noise did not reach the reference"
+                cost = reference_costs(solver, obj, mean)
+                X_ref = solver._state_seq_batch.numpy()
+                dev = census_solve(fx_static, R, state.numpy(), mean.numpy(), eps, X_ref)
+                ev = np.zeros(K, bool)
+                for m in dev:
+                    counts[m] += int((dev[m] > 1e-4).sum())
+                    worst[m] = max(worst[m], float(dev[m].max()))
+                    ev |= dev[m] > event_bar
+                total += K
+                key = f"{mi}_{i}"
+                out[f"state_{key}"] = state.numpy().copy(); out[f"mean_{key}"] = mean.numpy().copy()
+                out[f"Ustar_{key}"] = U_opt.numpy().copy(); out[f"Xstar_{key}"] = X_opt[0].numpy().copy()
+                out[f"w_{key}"] = solver._weights.numpy().copy(); out[f"cost_{key}"] = cost.numpy().copy()
+                out[f"Xs_{key}"] = X_ref[:, [T // 2, T], :].copy()
+                out[f"ev_k_{key}"] = np.nonzero(ev)[0].astype(np.int32)
+                out[f"ev_X_{key}"] = X_ref[ev].copy()
+                state = solver._state_seq_batch.new_tensor(X_opt[0, 5].tolist())      # crude closed loop, as run_case's "follow"
+                state[2] = (state[2] + math.pi) % (2 * math.pi) - math.pi
+    summary = dict(rollouts=total, over_1e4={str(m): counts[m] for m in counts}, max_dev={str(m): worst[m] for m in worst})
+    if store:
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name:14s} G={G} K={K} T={T} maps={len(maps)} solves/map={n_solves}: {total} rollouts, over 1e-4 by mode {counts}, "
+              f"max {worst} -> {os.path.getsize(path)/1024:.0f} KiB")
+    return summary
+
+
+def run_census():
+    """Stored census fixtures + a larger unstored sweep whose counts go to census_summary.json."""
+    import json
+    stored = {
+        "census_c2": run_census_case("census_c2", G=256, K=1024, T=50, maps=[("smooth", 0), ("smooth", 1), ("iid", 0), ("iid", 1)], n_solves=14),
+        "census_c5": run_census_case("census_c5", G=512, K=16384, T=100, maps=[("smooth", 0), ("iid", 0)], n_solves=3),
+    }
+    wide = {
+        "c2_wide": run_census_case("c2_wide", G=256, K=1024, T=50, maps=[(k, s) for k in ("smooth", "iid") for s in range(2, 10)], n_solves=40, store=False),
+        "c5_wide": run_census_case("c5_wide", G=512, K=16384, T=100, maps=[(k, s) for k in ("smooth", "iid") for s in range(1, 4)], n_solves=6, store=False),
+    }
+    meta = dict(torch_version=torch.__version__, modes={"0": "libm sin/cos, reference operation order", "1": "the spec: carried rotation, fused transit (default kernels)",
+                                                       "2": "bn_sincos_spec per step, reference operation order (BN_FLAG_REFERENCE_ORDER)"},
+                stored=stored, unstored_sweep=wide)
+    with open(os.path.join(HERE, "census_summary.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta["unstored_sweep"], indent=1))
+
+
 def main():
     pi = math.pi
     if sys.argv[1:] == ["boundary"]:
         return run_boundary_case()
+    if sys.argv[1:] == ["census"]:
+        return run_census()
     if sys.argv[1:] == ["ref5000"]:
         return run_case("ref5000", G=64, res=0.5, K=5000, T=50, risk_mean=smooth_risk_map(64, 9) * 0.7, risk_std=slip_std_map(64, 9),
                         metric="cvar", confidence=0.9, start=[8.0, 8.0, pi / 4], goal=torch.tensor([24, 24]), thr=0.3, n_solves=3,
@@ -599,6 +721,7 @@ def main():
         return run_env_case()
     if sys.argv[1:] == ["episodes"]:
         return run_episode_case()
+    run_census()
     run_boundary_case()
     run_env_case()
     run_episode_case()

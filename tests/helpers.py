@@ -150,3 +150,74 @@ def mppi_for_fixture(fx, **kw):
     return MPPI(horizon=int(fx["T"]), num_samples=int(fx["K"]), dim_state=3, dim_control=2, dynamics=dyn,
                 objectives=obj, sigmas=torch.tensor(fx["sigmas"]), lambda_=float(fx["lam"]),
                 device=torch.device("cuda"), seed=int(fx["seed"]), **kw)
+
+
+# ---- parity census (tests/golden/census_*.npz; DESIGN.md "Arithmetic spec and parity tiers") -------------------------------------
+# The reference ran at a BASELINE size on the oracle's portable noise stream; per solve the fixture holds slots T//2 and T of every
+# rollout and, for every rollout that left 2e-5 against any arithmetic mode at capture, the reference's full row.  A candidate
+# (an oracle mode, or the HIP path) is classified per rollout: within the 1e-4 trajectory tolerance, or not -- and every rollout
+# that is not must be a CELL FLIP: the candidate and the reference looked up different cells at some step t_cell (positions a
+# few ulp apart on either side of a cell boundary), agreed to a few ulp before it and left the tolerance only from there on.
+CENSUS_X_TOL = 1e-4          # trajectory tolerance against the reference
+CENSUS_PRE_FLIP_ULP = 4.0    # before the first cell mismatch a diverging rollout agrees with the reference to this many ulp
+# stated bounds on the share of rollouts beyond CENSUS_X_TOL (all of them cell flips), by arithmetic and horizon; observed at
+# capture (tests/golden/census_summary.json, 1.4 M rollouts): spec 3.1e-5 (T=50) / 1.4e-4 (T=100), reference order 0 / 1.5e-6
+CENSUS_RATE_BOUND = {"spec": {50: 1.2e-4, 100: 4e-4}, "reference_order": {50: 3e-5, 100: 3e-5}}
+
+
+def census_solves(fx):
+    for mi in range(int(fx["n_maps"])):
+        for i in range(int(fx["n_solves"])):
+            yield mi, i, f"{mi}_{i}"
+
+
+def census_eps(fx, mi, i):
+    from oracle import oracle as O
+    K, T = int(fx["K"]), int(fx["T"])
+    return O.portable_normal(int(fx[f"noise_seed_{mi}"]), i + 1, K * T * 2).reshape(K, T, 2)
+
+
+def census_oracle_params(fx, mi, trig):
+    from oracle import oracle as O
+    return O.make_params(int(fx["K"]), int(fx["T"]), int(fx["G"]), float(fx["res"]), fx[f"goal_{mi}"], thr=float(fx["thr"]),
+                         lambda_=float(fx["lam"]), sigma=fx["sigmas"].tolist(), trig=trig)
+
+
+def _census_cells(row, start, G, res):
+    """Cell (ix, iy) of states 0..T of one rollout: state 0 = the start, state t+1 = clamp(slot t) (robot_model.py:93-94,
+    grid_map.py:195-209 in float32)."""
+    T = row.shape[0] - 1
+    st = np.empty((T + 1, 2), np.float32)
+    st[0] = start[:2]
+    st[1:] = np.clip(row[:T, :2], np.float32(0), np.float32(G * res))
+    return np.clip(np.floor(st / np.float32(res)), 0, G - 1).astype(np.int64)
+
+
+def census_classify(fx, key, X):
+    """X (K,T+1,3): a candidate's trajectory batch for stored solve `key`.  Returns dict(beyond = rollouts beyond the
+    tolerance at the stored slots, pos_ulp (K,) = max position deviation there in ulp of the coordinate, theta = max heading
+    deviation); asserts that every rollout beyond the tolerance is a recorded event AND a cell flip."""
+    G, res = int(fx["G"]), float(fx["res"])
+    slots = fx["slots"]
+    ref = fx[f"Xs_{key}"]
+    d = np.abs(X[:, slots, :] - ref)
+    beyond = np.nonzero(d.reshape(d.shape[0], -1).max(1) > CENSUS_X_TOL)[0]
+    ev_k, ev_X = fx[f"ev_k_{key}"], fx[f"ev_X_{key}"]
+    where = {int(k): j for j, k in enumerate(ev_k)}
+    for k in beyond:
+        assert int(k) in where, f"{key}: rollout {k} left the tolerance but was no event at capture"
+    for k, j in where.items():                         # every recorded event, wherever the candidate is beyond the tolerance on it
+        dk = np.abs(X[k] - ev_X[j]).max(1)
+        if dk.max() <= CENSUS_X_TOL:
+            continue
+        t_dev = int(np.argmax(dk > CENSUS_X_TOL))
+        ca, cb = _census_cells(ev_X[j], fx[f"state_{key}"], G, res), _census_cells(X[k], fx[f"state_{key}"], G, res)
+        mism = np.nonzero((ca != cb).any(1))[0]
+        assert len(mism), f"{key}: rollout {k} leaves the tolerance at slot {t_dev} without a cell mismatch"
+        t_cell = int(mism[0])
+        assert 0 < t_cell <= t_dev + 1, f"{key}: rollout {k}: first cell mismatch at state {t_cell}, tolerance left at slot {t_dev}"
+        pre = np.abs(X[k, :t_cell, :2] - ev_X[j][:t_cell, :2])
+        ulp = np.spacing(np.abs(ev_X[j][:t_cell, :2]).astype(np.float32))
+        assert (pre <= CENSUS_PRE_FLIP_ULP * ulp).all(), f"{key}: rollout {k} is {float((pre / ulp).max()):.1f} ulp off BEFORE its first cell mismatch"
+    pos_ulp = (d[..., :2] / np.spacing(np.abs(ref[..., :2]).astype(np.float32))).reshape(d.shape[0], -1).max(1)
+    return dict(beyond=beyond, pos_ulp=pos_ulp, theta=d[..., 2].max(1))
