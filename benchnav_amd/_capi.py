@@ -26,8 +26,9 @@ BN_FLAG_ROLE_KERNEL = 256
 BN_FLAG_LEAN = 512
 BN_FLAG_LAT_KERNEL = 1024
 BN_FLAG_NO_OVERLAP = 2048
+BN_FLAG_REFERENCE_ORDER = 4096
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Config(C.Structure):
@@ -88,6 +89,8 @@ SYMBOLS = {
     "bn_mppi_reroll_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "bn_mppi_device_buffer": (C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "bn_mppi_solve_count": (C.c_uint64, [_H]),
+    "bn_mppi_arithmetic": (C.c_int32, [_H]),
+    "bn_mppi_launches_per_solve": (C.c_int32, [_H]),
     "bn_mppi_row_pitch": (C.c_int32, [_H]),
     "bn_mppi_kernel_ms": (C.c_int, [_H, _FP, _FP, C.POINTER(C.c_int32)]),
     "bn_mppi_algorithmic_bytes": (C.c_int64, [_H, C.c_int]),

@@ -122,6 +122,7 @@ struct bn_mppi {
     // writes solve i-1's tail (U*, X*, weights).  `tail_pending` = the latest solve's tail has not been
     // written yet; flush() launches the finish kernel for it.
     bool pipelined = false;
+    bool slow_path = false;          // rollout_wave_kernel + stand-alone tail, two launches per solve: BN_FLAG_REFERENCE_ORDER, dt |omega| > 0.5, horizons beyond the role kernels' LDS
     bool tail_pending = false;
     // device buffers
     float *d_map = nullptr, *d_state = nullptr, *d_goal = nullptr, *d_mean = nullptr, *d_eps = nullptr;
@@ -420,11 +421,14 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     for (int d = 0; d < 2; ++d)
         if (!(cfg->u_min[d] <= cfg->u_max[d]) || !(cfg->sigma[d] >= 0.0f))
             return fail(BN_ERR_INVALID, "need u_min <= u_max and sigma >= 0");
-    // The heading vector is carried by a small-angle rotation per step (rotate_spec, bn_device_math.h): its degree-6 polynomials
-    // are good to 1e-7 up to 0.5 rad per step (the reference's dt = 0.1, |omega| <= 1 give 0.1); the branch-free near form of the
-    // heading wrap after the first step needs less than pi as well.
-    if (!((double)cfg->dt * std::max(std::fabs((double)cfg->u_min[1]), std::fabs((double)cfg->u_max[1])) <= 0.5))
-        return fail(BN_ERR_INVALID, "dt * max|omega| must not exceed 0.5 rad per step");
+    // The default arithmetic carries the heading vector by a small-angle rotation per step (rotate_spec, bn_device_math.h): its
+    // degree-6 polynomials are good to 1e-7 up to 0.5 rad per step (the reference's dt = 0.1, |omega| <= 1 give 0.1), and the
+    // branch-free near form of the heading wrap needs less than pi.  The reference itself has no such bound (transit takes any
+    // delta_t, robot_model.py:60): beyond it the handle takes the reference-order arithmetic -- sincos_spec of every step's heading,
+    // general wrap -- exactly as if BN_FLAG_REFERENCE_ORDER had been given (bn_mppi_arithmetic() tells).
+    const bool big_step = !((double)cfg->dt * std::max(std::fabs((double)cfg->u_min[1]), std::fabs((double)cfg->u_max[1])) <= 0.5);
+    if (big_step && !std::isfinite((double)cfg->dt * ((double)cfg->u_max[1] - (double)cfg->u_min[1])))
+        return fail(BN_ERR_INVALID, "dt and the angular-velocity bounds must be finite");
     // The kernels share one gather between stage cost t and transit t+1; that needs the upper clamp
     // to land in the last cell, as it does for every reference GridMap (grid_map.py:42-50).
     const float span_x = (cfg->x_limits[1] - cfg->x_limits[0]) / cfg->resolution;
@@ -468,6 +472,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.seed = cfg->seed;
     p.store_u = (cfg->flags & BN_FLAG_STORE_CONTROLS) ? 1 : 0;
     p.lean = (cfg->flags & BN_FLAG_LEAN) ? 1 : 0;
+    p.ref_order = ((cfg->flags & BN_FLAG_REFERENCE_ORDER) || big_step) ? 1 : 0;
     // Workgroup i of a launch runs on XCD i % 8 (observed, used for speed only).  xs = 3 interleaves 8 instances along grid x
     // so that the workgroups of one instance share an XCD's L2 (rollout_grid); measured SLOWER (64 instances: 29.2 vs 28.1 us,
     // 60: 28.5 vs 24.9): the dispatcher then fills the CUs unevenly (3 to 5 workgroups per CU instead of 4, tools/block_trace.py)
@@ -487,11 +492,28 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     // often (K=16384 T=100: 27.4 -> 28.5 us per solve).
     p.WN = std::min(p.G + 1, 2 * p.reach + 1);
     const size_t lds_budget = 160 * 1024;
-    if ((cfg->flags & BN_FLAG_NO_LDS_WINDOW) || bn::rollout_lds_bytes(p) > lds_budget) p.WN = 0;
-    if (bn::rollout_lds_bytes(p) > lds_budget) {
-        delete h;
-        return fail(BN_ERR_INVALID, "horizon %d needs %zu B of LDS for the control tile (> 160 KiB)", p.T,
-                    bn::rollout_lds_bytes(p));
+    // The clamp-free window gather (trav_window) relies on the raw cell of an in-limits position being <= G, the guard row / column:
+    // true for every reference GridMap (limits span exactly G cells, grid_map.py:42-50).  Limits that span MORE cells than the grid
+    // has put raw cells beyond the guard for positions clamped to the upper limit; such a geometry takes the clamped gather from
+    // global memory (the reference's index clamp, grid_map.py:209), like BN_FLAG_NO_LDS_WINDOW.
+    const bool wide_limits = span_x > (float)cfg->grid_size * (1.0f + 1e-6f) || span_y > (float)cfg->grid_size * (1.0f + 1e-6f);
+    if ((cfg->flags & BN_FLAG_NO_LDS_WINDOW) || wide_limits) p.WN = 0;
+    // Slow path: the reference-order arithmetic, or a horizon whose control tile does not fit the role kernels' LDS
+    // (MPPI.__init__ takes any horizon, mppi.py:25).  The one-wave kernel keeps its controls in HBM and has no tile: rollouts +
+    // stand-alone tail, two launches per solve, one stream.
+    h->slow_path = p.ref_order != 0;
+    if (!h->slow_path) {
+        if (bn::rollout_lds_bytes(p) > lds_budget) p.WN = 0;
+        if (bn::rollout_lds_bytes(p) > lds_budget) { h->slow_path = true; p.WN = wide_limits || (cfg->flags & BN_FLAG_NO_LDS_WINDOW) ? 0 : std::min(p.G + 1, 2 * p.reach + 1); }
+    }
+    if (h->slow_path) {
+        const bool sampled = (cfg->flags & BN_FLAG_SAMPLED_SLIP) != 0;
+        if (bn::wave_lds_bytes(p) > lds_budget || (sampled && bn::finish_lds_bytes_for(p, true) > lds_budget)) p.WN = 0;
+        const size_t need = sampled ? sizeof(float) * (4 * (size_t)p.T + 2 * (size_t)p.T * bn::kUPad + 64) : bn::wave_lds_bytes(p);
+        if (need > lds_budget || bn::finish_lds_bytes_for(p, sampled) > lds_budget) {
+            delete h;
+            return fail(BN_ERR_INVALID, "horizon %d needs %zu B of LDS even on the slow path (> 160 KiB)", p.T, std::max(need, bn::finish_lds_bytes_for(p, sampled)));
+        }
     }
 
     {
@@ -518,10 +540,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     if (!p.lean) alloc(&h->d_X, B * (T + 1) * 3 * (size_t)p.Kp * 4);      // lean mode never materialises _state_seq_batch
     alloc(&h->d_mean_used, B * T * 2 * 4);
     // the throughput kernel keeps its controls in this buffer instead of an LDS tile, requested or not
-    const bool want_wave = !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_ROLE_KERNEL | BN_FLAG_SAMPLED_SLIP)) && p.nblk <= 32 &&
+    const bool want_wave = !h->slow_path && !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_ROLE_KERNEL | BN_FLAG_SAMPLED_SLIP)) && p.nblk <= 32 &&
                            ((cfg->flags & BN_FLAG_WAVE_KERNEL) ||
                             (((size_t)p.B + 1) * (p.nblk + 1) > (size_t)h->n_cus && wave_kernel_is_faster(p, h->resident_wgs, h->n_cus)));
-    if (p.store_u || want_wave) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
+    if (p.store_u || want_wave || h->slow_path) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
     for (int q = 0; q < kSlots; ++q) {
         alloc(&h->d_cost[q], B * K * 4);
         alloc(&h->d_part[q], B * (size_t)p.nblk * (2 + 2 * T) * 4);
@@ -553,7 +575,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats; p.mean_used = h->d_mean_used;
     // every rollout workgroup re-merges the previous solve's nblk partials: only worth it while they are few
     p.slip_on = (cfg->flags & BN_FLAG_SAMPLED_SLIP) ? 1 : 0;
-    h->pipelined = !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= kPipelinedMaxBlocks && !p.slip_on;
+    h->pipelined = !h->slow_path && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= kPipelinedMaxBlocks && !p.slip_on;
     // throughput kernel: launches with more workgroups than the role kernel keeps resident in one round (4 per CU)
     h->wave_kernel = h->pipelined && want_wave;
     // latency variant: every workgroup (rollouts + aux) alone on a CU -- with room left for one instance of an overlapped successor
@@ -582,7 +604,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     h->role_overlap = h->pipelined && !h->lat_kernel && !(cfg->flags & BN_FLAG_NO_OVERLAP);
     if (const char *e = std::getenv("BN_ROLE_OVERLAP")) h->role_overlap = h->role_overlap && e[0] != '0';   // experiments
     // the deterministic kernel's ticket path (K > 4096: one launch per solve, merge by the last workgroup) overlaps its launches as well
-    const bool ticket_det = !p.slip_on && !h->pipelined && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 1024 &&
+    const bool ticket_det = !h->slow_path && !p.slip_on && !h->pipelined && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 1024 &&
                             bn::finish_lds_bytes(p) + 256 <= bn::rollout_lds_bytes(p);
     h->ticket_overlap = (ticket_det || (!(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p))) && !(cfg->flags & BN_FLAG_NO_OVERLAP) &&
                         !std::getenv("BN_NO_TICKET_OVERLAP");
@@ -615,7 +637,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         alloc(&h->d_ticket, (size_t)p.B * 65 * 4);
         alloc(&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4);
         p.ticket = h->d_ticket; p.gpart = h->d_gpart;
-        h->ticket_mode = !(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p);
+        h->ticket_mode = !h->slow_path && !(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p);
     } else if (ticket_det) {
         // K > 4096: too many partials for every workgroup to re-merge; the last workgroup of a launch merges them
         for (int q = 0; q < kSlots; ++q) {
@@ -977,8 +999,11 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     }
     if (p.slip_on) {
         BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
-    } else
-    BN_HIP(bn::launch_rollout(p, mode, h->stream));
+    } else {
+        if (h->slow_path) p.wave_kernel = 1;                 // no control tile in LDS, any horizon; REF arithmetic when p.ref_order
+        else if (!p.store_u) p.U = nullptr;                  // (the buffer may exist for the throughput kernel only)
+        BN_HIP(bn::launch_rollout(p, mode, h->stream));
+    }
     if (prof) BN_HIP(hipEventRecord(ev[1], h->stream));
     if (shard_rollout) {
         if (prof) BN_HIP(hipEventRecord(ev[2], h->stream));
@@ -1248,7 +1273,9 @@ int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, b
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_episode_async");
-    if (!h->pipelined) return fail(BN_ERR_INVALID, "the device-side closed loop needs the pipelined mode (num_samples <= 2048)");
+    if (h->slow_path) return fail(BN_ERR_INVALID, "the fused device-side closed loop is not available on the slow path (BN_FLAG_REFERENCE_ORDER, dt * |omega| > 0.5, "
+                                                   "or a horizon beyond the role kernels' LDS): drive bn_mppi_forward_async + bn_mppi_env_step instead");
+    if (!h->pipelined) return fail(BN_ERR_INVALID, "the device-side closed loop needs the pipelined mode (num_samples <= 4096)");
     if (n_steps < 1) return fail(BN_ERR_INVALID, "n_steps must be >= 1");
     BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;            // anything pending belongs to the pre-episode state
@@ -1656,6 +1683,9 @@ int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size
 }
 
 uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves : 0; }
+
+int32_t bn_mppi_arithmetic(const bn_mppi_t *h) { return h ? h->p.ref_order : -1; }
+int32_t bn_mppi_launches_per_solve(const bn_mppi_t *h) { return h ? ((h->pipelined || h->ticket_mode) ? 1 : 2) : -1; }
 
 int32_t bn_mppi_row_pitch(const bn_mppi_t *h) { return h ? h->p.Kp : 0; }
 

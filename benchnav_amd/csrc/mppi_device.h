@@ -228,11 +228,28 @@ __device__ __forceinline__ void chain_prepare(const SolveParams &p, Chain &c, fl
 
 // PREP: the caller's loop hands over the NEXT step's controls (u0n, u1n) and chain_prepare runs for them at the end of this step,
 // under the gather's latency (the role kernels' chain wave); otherwise the step prepares itself from its own controls first.
-template <int GEO, bool LDSWIN, bool FIRST, bool THETA = true, bool PREP = false, int ASMIDX = 0>
+// REF (BN_FLAG_REFERENCE_ORDER): the transit as the reference writes it -- sin / cos of THIS step's heading (sincos_spec), then
+// x + ((trav v) cos) dt, y + ((trav v) sin) dt, theta + (trav omega) dt in that operation order (robot_model.py:86-88), the general
+// heading wrap at every step (no bound on dt |omega|).  c.sn / c.cs / c.G / c.wq are not used.  The oracle's trig = 2.
+template <int GEO, bool LDSWIN, bool FIRST, bool THETA = true, bool PREP = false, int ASMIDX = 0, bool REF = false>
 __device__ __forceinline__ void chain_step(const SolveParams &p, const float *win, const float *__restrict__ map,
                                            const Win w, Chain &c, float u0, float u1, float &xn, float &yn, float &tn,
                                            float u0n = 0.0f, float u1n = 0.0f)
 {
+    if constexpr (REF) {
+        static_assert(THETA && !PREP, "the reference-order step integrates its own heading");
+        float sn, cs;
+        sincos_spec(c.th, sn, cs);
+        const float tv = c.trav * u0;
+        xn = c.x + (tv * cs) * p.dt;                                   // :86
+        yn = c.y + (tv * sn) * p.dt;                                   // :87
+        tn = c.th + (c.trav * u1) * p.dt;                              // :88
+        c.th = wrap_angle(tn);                                         // :90
+        c.x = clampf(xn, p.x0, p.x_hi);                                // :93
+        c.y = clampf(yn, p.y0, p.y_hi);                                // :94
+        c.trav = LDSWIN ? trav_window<GEO, 0>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
+        return;
+    }
     if (!PREP) chain_prepare(p, c, u0, u1);
     // Position strand first: update, clamp, cell index, and the gather goes out; the heading strand (rotation, 7
     // instructions) then runs under the gather's LDS latency.  The scheduling barrier keeps the compiler from
@@ -349,12 +366,25 @@ __device__ __forceinline__ int slip_cell_window(const SolveParams &p, const Win 
 // pairs: state (x, y, th) with heading (sn, cs) and window cell e advances; (xn, yn, tn) is what slot t keeps.
 struct SlipChain { float x, y, th, sn, cs; int e; };
 
-template <int GEO, bool FIRST>
+template <int GEO, bool FIRST, bool REF = false>
 __device__ __forceinline__ void slip_chain_step(const SolveParams &p, const float2 *win2, const Win w, SlipChain &c, float u0,
                                                 float u1, float z, float &xn, float &yn, float &tn)
 {
     const float2 ms = win2[c.e];
     const float trav = trav_from_slip(ms.x, ms.y, z);                  // robot_model.py:75
+    if constexpr (REF) {                                               // the reference's operation order (chain_step<..., REF>)
+        float sn, cs;
+        sincos_spec(c.th, sn, cs);
+        const float tv = trav * u0;
+        xn = c.x + (tv * cs) * p.dt;
+        yn = c.y + (tv * sn) * p.dt;
+        tn = c.th + (trav * u1) * p.dt;
+        c.th = wrap_angle(tn);
+        c.x = clampf(xn, p.x0, p.x_hi);
+        c.y = clampf(yn, p.y0, p.y_hi);
+        c.e = slip_cell_window<GEO>(p, w, c.x, c.y);
+        return;
+    }
     const float g = u0 * p.dt;                                         // the transit arithmetic of chain_step
     const float dth = trav * (u1 * p.dt);
     xn = __builtin_fmaf(trav, g * c.cs, c.x);
@@ -767,7 +797,7 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 // device-scope loads, and write EVERY output with device-scope (sc1, write-through) stores: the tails of consecutive solves run in
 // different kernels, possibly on different XCDs, and write the same addresses -- the tail counter orders the stores themselves, but
 // a plain store may sit dirty in its XCD's L2 until its kernel ends, and which kernel ends last is not ordered by anything.
-template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false, bool WIDE = false>
+template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false, bool WIDE = false, bool REF = false>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
 {
@@ -883,7 +913,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
                 c.x = sx; c.y = sy; c.th = sth;
                 sincos_spec(c.th, c.sn, c.cs);
                 c.e = slip_cell_safe<GEO, true>(p, w, sx, sy);
-                slip_chain_step<GEO, true>(p, win2, w, c, us[0], us[1], zol[0], xn, yn, tn);
+                slip_chain_step<GEO, true, REF>(p, win2, w, c, us[0], us[1], zol[0], xn, yn, tn);
                 Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
                 int t = 1;
                 for (; t + 4 <= T; t += 4) {                 // controls and draws of four steps read up front
@@ -892,12 +922,12 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
                     for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; uq[i][2] = zol[t + i]; }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        slip_chain_step<GEO, false>(p, win2, w, c, uq[i][0], uq[i][1], uq[i][2], xn, yn, tn);
+                        slip_chain_step<GEO, false, REF>(p, win2, w, c, uq[i][0], uq[i][1], uq[i][2], xn, yn, tn);
                         Xs[3 * (t + i)] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
                     }
                 }
                 for (; t < T; ++t) {
-                    slip_chain_step<GEO, false>(p, win2, w, c, us[2 * t], us[2 * t + 1], zol[t], xn, yn, tn);
+                    slip_chain_step<GEO, false, REF>(p, win2, w, c, us[2 * t], us[2 * t + 1], zol[t], xn, yn, tn);
                     Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
                 }
                 Xs[3 * T] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
@@ -909,10 +939,18 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
                 for (int t = 0; t < T; ++t) {
                     const int e = slip_cell_safe<GEO, false>(p, w, x, y);
                     const float trav = trav_from_slip(map[e], sg[e], zol[t]);
+                    if constexpr (REF) {
+                        sincos_spec(th, sn, cs);
+                        const float tv = trav * us[2 * t];
+                        xn = x + (tv * cs) * p.dt; yn = y + (tv * sn) * p.dt;
+                        tn = th + (trav * us[2 * t + 1]) * p.dt;
+                        th = wrap_angle(tn);
+                    } else {
                     const float g = us[2 * t] * p.dt, dth = trav * (us[2 * t + 1] * p.dt);
                     xn = __builtin_fmaf(trav, g * cs, x); yn = __builtin_fmaf(trav, g * sn, y);
                     tn = theta_step(th, dth, t == 0);
                     rotate_spec(cs, sn, dth);
+                    }
                     Xs[3 * t] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
                     x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi);
                 }
@@ -930,7 +968,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
         float *Xs = xl;                              // staged in LDS, written out coalesced below
         float xn, yn, tn;
-        chain_step<GEO, LDSWIN, true>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
+        chain_step<GEO, LDSWIN, true, true, false, 0, REF>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
         Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
         int t = 1;
         for (; t + 4 <= T; t += 4) {                       // controls of four steps read up front (LDS latency off the chain)
@@ -939,12 +977,12 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                chain_step<GEO, LDSWIN, false>(p, win, map, w, c, uq[i][0], uq[i][1], xn, yn, tn);
+                chain_step<GEO, LDSWIN, false, true, false, 0, REF>(p, win, map, w, c, uq[i][0], uq[i][1], xn, yn, tn);
                 Xs[3 * (t + i) + 0] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
             }
         }
         for (; t < T; ++t) {
-            chain_step<GEO, LDSWIN, false>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn);
+            chain_step<GEO, LDSWIN, false, true, false, 0, REF>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn);
             Xs[3 * t + 0] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
         }
         Xs[3 * T + 0] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
@@ -1132,5 +1170,6 @@ hipError_t launch_rollout_role_philox(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_kt2(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_t2k(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_wave(const SolveParams &p, EpsMode mode, hipStream_t s);
+hipError_t launch_rollout_wave_ref(const SolveParams &p, EpsMode mode, hipStream_t s);   // rollout_wave_ref.hip
 
 }  // namespace bn

@@ -38,6 +38,9 @@ struct SolveParams {
     int aux_prio;        // the aux workgroups run at wave priority 3: set when the launch exceeds one resident round, so that they
                          // start late (in slots freed by the first rollout workgroups) and must not finish last
     int lean;            // lean mode: the (K,T+1,3) trajectory batch is not materialised (bn_mppi_reroll regenerates rows on demand)
+    int ref_order;       // BN_FLAG_REFERENCE_ORDER (or dt * max|omega| > 0.5): every transit evaluates sincos_spec of its own heading and
+                         // updates in the reference's operation order, x + ((trav v) cos) dt (robot_model.py:86-88) -- the oracle's trig = 2.
+                         // Served by the one-wave kernel + stand-alone tail, two launches per solve (chain_step<..., REF = true>)
     float res, inv_res;
     float x0, y0;        // index origin == lower clamp (reference grid_map.py:199-201, robot_model.py:93-94)
     float x_hi, y_hi;    // upper clamp
@@ -137,6 +140,7 @@ inline dim3 rollout_grid(const SolveParams &p, bool aux)
 
 size_t rollout_lds_bytes(const SolveParams &p);
 size_t finish_lds_bytes(const SolveParams &p);
+size_t finish_lds_bytes_for(SolveParams p, bool sampled);   // ... before p.slip_on is set (bn_mppi_create)
 size_t wave_lds_bytes(const SolveParams &p);
 size_t lat_lds_bytes(const SolveParams &p);       // 0 when the latency variant cannot take this configuration
 int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer for the headline rollout kernel (diagnostics)

@@ -29,11 +29,11 @@ namespace {
 // Finish kernel.  grid = B, block = NT (320, or 1024 above 32 workgroups): finish_body for the latest solve (also the flush of the
 // pipelined mode).
 // ------------------------------------------------------------------------------
-template <int GEO, bool LDSWIN, int NT>
+template <int GEO, bool LDSWIN, int NT, bool REF>
 __global__ __launch_bounds__(NT) void finish_kernel(const SolveParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    finish_body<GEO, LDSWIN, NT, true, false, true>(p, blockIdx.x, p.part, p.cost, p.state, smem);
+    finish_body<GEO, LDSWIN, NT, true, false, true, REF>(p, blockIdx.x, p.part, p.cost, p.state, smem);
 }
 
 // ------------------------------------------------------------------------------
@@ -67,18 +67,21 @@ __global__ __launch_bounds__(256) void reroll_kernel(const SolveParams p, int b,
         c.x = sx; c.y = sy; c.th = sth;                   // mppi.py:160
         sincos_spec(c.th, c.sn, c.cs);
         c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
+        const bool ref = p.ref_order != 0;                    // (uniform; this kernel is not on the solve path)
         for (int t = 0; t < T; t += 2) {
             float e[4], xn, yn, tn;
             noise_pair<EPS>(p, b, k, t, e);
             const float u0 = clampf(ml[2 * t] + p.sigma0 * e[0], p.umin0, p.umax0);          // mppi.py:152-157
             const float u1 = clampf(ml[2 * t + 1] + p.sigma1 * e[1], p.umin1, p.umax1);
-            if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+            if (ref) chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+            else if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
             else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, u0, u1, xn, yn, tn);
             Xo[3 * t] = xn; Xo[3 * t + 1] = yn; Xo[3 * t + 2] = tn;
             if (t + 1 < T) {
                 const float v0 = clampf(ml[2 * t + 2] + p.sigma0 * e[2], p.umin0, p.umax0);
                 const float v1 = clampf(ml[2 * t + 3] + p.sigma1 * e[3], p.umin1, p.umax1);
-                chain_step<GEO, LDSWIN, false>(p, win, map, w, c, v0, v1, xn, yn, tn);
+                if (ref) chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, v0, v1, xn, yn, tn);
+                else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, v0, v1, xn, yn, tn);
                 Xo[3 * t + 3] = xn; Xo[3 * t + 4] = yn; Xo[3 * t + 5] = tn;
             }
         }
@@ -125,9 +128,11 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
     c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
     float *Xk = Xall ? Xall + ((size_t)b * NA + k) * (T + 1) * 3 : nullptr;
     float cost = 0.0f;
+    const bool ref = p.ref_order != 0;
     for (int t = 0; t < T; ++t) {
         float xn, yn, tn;
-        if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+        if (ref) chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+        else if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
         else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, u0, u1, xn, yn, tn);
         if (Xk && active) { Xk[3 * t] = xn; Xk[3 * t + 1] = yn; Xk[3 * t + 2] = tn; }
         const float dx = xn - hx, dy = yn - hy;
@@ -361,20 +366,26 @@ __global__ void philox_noise_kernel(float *__restrict__ eps, uint64_t seed, uint
     }
 }
 
-template <int GEO, bool LDSWIN>
-hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
+template <int GEO, bool LDSWIN, bool REF>
+hipError_t launch_finish_r(const SolveParams &p, hipStream_t s)
 {
     const size_t lds = finish_lds_bytes(p);
     if (p.nblk > 32) {                    // sizes the pipelined mode does not take: a wide tail (merge tiles, weights)
-        hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN, kWideFinishThreads>, lds);
+        hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN, kWideFinishThreads, REF>, lds);
         if (e != hipSuccess) return e;
-        finish_kernel<GEO, LDSWIN, kWideFinishThreads><<<dim3(p.B), dim3(kWideFinishThreads), lds, s>>>(p);
+        finish_kernel<GEO, LDSWIN, kWideFinishThreads, REF><<<dim3(p.B), dim3(kWideFinishThreads), lds, s>>>(p);
     } else {
-        hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN, kFinishThreads>, lds);
+        hipError_t e = ensure_lds(finish_kernel<GEO, LDSWIN, kFinishThreads, REF>, lds);
         if (e != hipSuccess) return e;
-        finish_kernel<GEO, LDSWIN, kFinishThreads><<<dim3(p.B), dim3(kFinishThreads), lds, s>>>(p);
+        finish_kernel<GEO, LDSWIN, kFinishThreads, REF><<<dim3(p.B), dim3(kFinishThreads), lds, s>>>(p);
     }
     return hipGetLastError();
+}
+
+template <int GEO, bool LDSWIN>
+hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
+{
+    return p.ref_order ? launch_finish_r<GEO, LDSWIN, true>(p, s) : launch_finish_r<GEO, LDSWIN, false>(p, s);
 }
 
 }  // namespace
@@ -405,6 +416,12 @@ size_t finish_lds_bytes(const SolveParams &p)
     const size_t slip = p.slip_on ? 2 * (size_t)p.WN * p.WN + (size_t)p.T + 16 : 0;    // (mean, std) window + the draws of X*
     const size_t groups = (p.nblk > 64 && p.nblk <= 64 * 16) ? (size_t)((p.nblk + 15) / 16) * (2 + 2 * (size_t)p.T) : 0;   // two-level merge rows
     return sizeof(float) * ((size_t)p.WN * p.WN + 2 * (size_t)p.T + 3 * ((size_t)p.T + 1) + (size_t)p.nblk + 32 + groups + slip);
+}
+
+size_t finish_lds_bytes_for(SolveParams p, bool sampled)
+{
+    p.slip_on = sampled ? 1 : 0;
+    return finish_lds_bytes(p);
 }
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)

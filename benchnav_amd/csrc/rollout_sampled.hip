@@ -240,10 +240,19 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         const float u0 = Ul[(2 * t) * kUPad + lane], u1 = Ul[(2 * t + 1) * kUPad + lane];
         const int e = slip_cell_safe<GEO, false>(p, w, x, y);
         const float trav = trav_from_slip(mu[e], sg[e], zq[t & 1]);                                     // robot_model.py:75
-        const float g = u0 * p.dt, dth = trav * (u1 * p.dt);                                           // the transit arithmetic of chain_step
-        const float xn = __builtin_fmaf(trav, g * cs, x), yn = __builtin_fmaf(trav, g * sn, y);
-        const float tn = theta_step(th, dth, t == 0);
-        rotate_spec(cs, sn, dth);                                                                       // carried heading vector
+        float xn, yn, tn;
+        if (p.ref_order) {                                                                              // BN_FLAG_REFERENCE_ORDER (chain_step<..., REF>)
+            sincos_spec(th, sn, cs);
+            const float tv = trav * u0;
+            xn = x + (tv * cs) * p.dt; yn = y + (tv * sn) * p.dt;
+            tn = th + (trav * u1) * p.dt;
+            th = wrap_angle(tn);
+        } else {
+            const float g = u0 * p.dt, dth = trav * (u1 * p.dt);                                       // the transit arithmetic of chain_step
+            xn = __builtin_fmaf(trav, g * cs, x); yn = __builtin_fmaf(trav, g * sn, y);
+            tn = theta_step(th, dth, t == 0);
+            rotate_spec(cs, sn, dth);                                                                   // carried heading vector
+        }
         float *Xt = Xb + (size_t)(3 * t) * Kp;
         Xt[0] = xn; Xt[Kp] = yn; Xt[2 * Kp] = tn;
         x = clampf(xn, p.x0, p.x_hi); y = clampf(yn, p.y0, p.y_hi);
@@ -310,7 +319,7 @@ bool sampled_fused(const SolveParams &p)
     // the multi-wave kernel needs the LDS window and room for its tiles; its LDS also holds the aux tail / merge scratch
     const size_t need = sizeof(float) * sampled_lds_floats(p.T, p.WN);
     const size_t tail = finish_lds_bytes(p) + sizeof(float) * 64;
-    return p.slip_on && p.WN > 0 && need <= 160 * 1024 && tail <= need && p.nblk <= 1024;
+    return p.slip_on && !p.ref_order && p.WN > 0 && need <= 160 * 1024 && tail <= need && p.nblk <= 1024;
 }
 
 

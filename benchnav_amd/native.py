@@ -32,7 +32,7 @@ class NativeMPPI:
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
                  profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False, kernel: str = "auto",
-                 lean: bool = False, overlap: bool = True):
+                 lean: bool = False, overlap: bool = True, reference_order: bool = False):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -62,6 +62,7 @@ class NativeMPPI:
                      | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0)
                      | (_capi.BN_FLAG_LEAN if lean else 0)
                      | (0 if overlap else _capi.BN_FLAG_NO_OVERLAP)
+                     | (_capi.BN_FLAG_REFERENCE_ORDER if reference_order else 0)
                      | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL, "lat": _capi.BN_FLAG_LAT_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
@@ -295,6 +296,13 @@ class NativeMPPI:
 
     def solve_count(self) -> int:
         return int(self._lib.bn_mppi_solve_count(self._h))
+
+    def arithmetic(self) -> str:
+        """'spec' (carried heading vector, fused transit: the default) or 'reference_order' (robot_model.py:86-88 as written)."""
+        return "reference_order" if self._lib.bn_mppi_arithmetic(self._h) == 1 else "spec"
+
+    def launches_per_solve(self) -> int:
+        return int(self._lib.bn_mppi_launches_per_solve(self._h))
 
     def kernel_ms(self):
         r, f, n = C.c_float(), C.c_float(), C.c_int32()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BN_MPPI_ABI_VERSION 2
+#define BN_MPPI_ABI_VERSION 3
 
 typedef enum bn_status {
     BN_OK = 0,
@@ -83,8 +83,18 @@ enum {
     BN_FLAG_LEAN = 1u << 9,            /* lean mode: _state_seq_batch (mppi.py:119-125) is not materialised -- 70 % of a solve's
                                           HBM bytes; bn_mppi_get_states / bn_mppi_get_top_samples / bn_mppi_reroll_async
                                           regenerate the requested rows of the latest solve bit-identically on demand */
-    BN_FLAG_SAMPLED_SLIP = 1u << 6     /* BASELINE config 3: every traversability lookup of the rollouts draws
+    BN_FLAG_SAMPLED_SLIP = 1u << 6,    /* BASELINE config 3: every traversability lookup of the rollouts draws
                                           slip ~ Normal(map, slip_std)[cell]; see bn_mppi_set_slip_std */
+    BN_FLAG_REFERENCE_ORDER = 1u << 12 /* the transit in the REFERENCE's own operation order, robot_model.py:75-95: sin / cos of every
+                                          step's heading, x + ((trav v) cos) dt, theta + (trav omega) dt, the general heading wrap.
+                                          The default arithmetic (heading vector carried by a rotation per step, one fused update) leaves
+                                          positions 1-2 ulp from the reference's, and about one rollout in 30 000 (T = 50; one in 7 000 at
+                                          T = 100) then lands in a neighbouring cell and leaves the 1e-4 trajectory tolerance from there on
+                                          (tests/golden/census_*.npz); with this flag none did in 0.7 M rollouts at T = 50 and
+                                          one in 0.7 M at T = 100 -- the level of libm against the reference's own SLEEF.  Costs speed: the
+                                          solve is the one-wave kernel plus a stand-alone tail, two launches on one stream (the same slow
+                                          path serves horizons beyond the role kernels' LDS, and dt * max|omega| > 0.5 selects this arithmetic
+                                          by itself).  bn_mppi_arithmetic() tells which arithmetic a handle runs. */
 };
 
 /*
@@ -324,6 +334,11 @@ int32_t bn_mppi_row_pitch(const bn_mppi_t *h);
 
 /* Number of solves enqueued so far (the Philox stream position). */
 uint64_t bn_mppi_solve_count(const bn_mppi_t *h);
+
+/* 0: the default arithmetic (carried heading vector, fused transit); 1: the reference's operation order
+ * (BN_FLAG_REFERENCE_ORDER, or selected because dt * max|omega| > 0.5).  Kernel launches one solve costs: 1 or 2. */
+int32_t bn_mppi_arithmetic(const bn_mppi_t *h);
+int32_t bn_mppi_launches_per_solve(const bn_mppi_t *h);
 
 /* With BN_FLAG_PROFILE: mean duration in milliseconds of the rollout kernel and of
  * the finish kernel over the solves since the last call (HIP events on the

@@ -682,12 +682,92 @@ def run_census_case(name, *, G, K, T, maps, n_solves, res=0.5, thr=0.3, lam=0.5,
     return summary
 
 
+def run_census_sampled_case(name="census_c3", *, G=256, K=8192, T=50, res=0.5, thr=0.3, lam=0.5, seed=4242, event_bar=2e-5):
+    """BASELINE configs[2] at its full size (K=8192, T=50, 256x256, slip sampled per lookup) from the reference's own
+    observation-mode components, exactly as run_sampled_case drives them (the reference's MPPI class cannot run this mode,
+    SURVEY 0.9), but on the portable noise stream so that nothing of the 7 MB of draws has to be stored: eps = stream 1,
+    the transit draws of step t = stream 100 + t, the cost draws of slot t = stream 1000 + t, the optimal rollout's draw of
+    step t = stream 2000 + t.  torch.normal(loc, scale) -- what Normal.sample() calls -- is z * scale + loc on a standard
+    normal z (checked bit for bit by run_sampled_case's capture); here z comes from the portable stream.  Stored like a
+    census solve (key "0_0") so that helpers.census_classify applies."""
+    from oracle import oracle as O
+    sig = torch.tensor([0.5, 0.5])
+    inst = make_instance(G, seed=5, resolution=res, kind="smooth")
+    mean_map, std_map, goal = inst.risk * 0.8, slip_std_map(G, 5), inst.goal
+    gm = _env_grid_map(G, res, mean_map, std_map)
+    dyn = UnicycleModel(gm, ModelConfig(mode="observation"), device="cpu")
+    obj = Objectives(dyn, goal_pos=goal, stuck_threshold=thr)
+    real_normal = torch.normal
+    # the identity the substitution rests on, on this torch build
+    torch.manual_seed(3); a = real_normal(mean_map, std_map); torch.manual_seed(3); zz = torch.empty_like(mean_map).normal_()
+    assert torch.equal(zz * std_map + mean_map, a), "torch.normal(loc, scale) is not z * scale + loc on this build"
+    stream = {"next": None}
+
+    def portable_normal(loc, scale, *a_, **k_):
+        z = torch.from_numpy(O.portable_normal(seed, stream["next"], loc.numel())).reshape(loc.shape)
+        stream["next"] += 1
+        return z * scale + loc
+
+    torch.normal = portable_normal
+    try:
+        state = inst.start.clone()
+        g = torch.Generator().manual_seed(seed)
+        mean = (torch.randn(T, 2, generator=g) * 0.2 + torch.tensor([0.6, 0.0])).clamp(torch.tensor([0.0, -1.0]), torch.tensor([1.0, 1.0]))
+        eps = torch.from_numpy(O.portable_normal(seed, 1, K * T * 2)).reshape(K, T, 2)
+        U = torch.clamp(mean + eps * sig, dyn.min_action, dyn.max_action)            # mppi.py:146-153
+        inv_cov = torch.inverse(torch.diag(sig ** 2))
+        X = torch.zeros(K, T + 1, 3)
+        X[:, 0, :] = state
+        stream["next"] = 100
+        for t in range(T):                                                            # mppi.py:158-163
+            X[:, t + 1, :], _ = dyn.transit(X[:, t, :], U[:, t, :])
+        assert stream["next"] == 100 + T
+        stage, act = torch.zeros(K, T), torch.zeros(K, T)
+        stream["next"] = 1000
+        for t in range(T):                                                            # mppi.py:168-181
+            stage[:, t] = obj.stage_cost(X[:, t, :], U[:, t, :])
+            act[:, t] = mean[t] @ inv_cov @ U[:, t].T
+        term = obj.terminal_cost(X[:, -1, :])
+        assert stream["next"] == 1000 + T + 1
+        cost = torch.sum(stage, dim=1) + term + torch.sum(lam * act, dim=1)           # mppi.py:184-190
+        w = torch.softmax(-cost / lam, dim=0)
+        Ustar = torch.sum(w.view(K, 1, 1) * U, dim=0)                                 # mppi.py:193-199
+        Xs = torch.zeros(1, T + 1, 3)
+        Xs[:, 0, :] = state
+        stream["next"] = 2000
+        for t in range(T):                                                            # mppi.py:202-214
+            Xs[:, t + 1, :], _ = dyn.transit(Xs[:, t, :], Ustar[t].unsqueeze(0))
+    finally:
+        torch.normal = real_normal
+    sys.path.append(os.path.dirname(HERE))
+    from helpers import census_sampled_draws      # tests/helpers.py: the tests regenerate the draws the same way
+    zt, zc, zo = census_sampled_draws(seed, K, T)
+    X_ref = X.numpy()
+    ev = np.zeros(K, bool)
+    counts, worst = {}, {}
+    for trig in (0, 1, 2):
+        p = O.make_params(K, T, G, res, goal.numpy(), thr=thr, lambda_=lam, trig=trig)
+        got = O.solve_sampled(p, mean_map.numpy(), std_map.numpy(), state.numpy(), mean.numpy(), eps.numpy(), zt, zc, zo)
+        dev = np.abs(got["X"] - X_ref).reshape(K, -1).max(1)
+        counts[trig], worst[trig] = int((dev > 1e-4).sum()), float(dev.max())
+        ev |= dev > event_bar
+    out = dict(G=G, res=res, K=K, T=T, thr=thr, lam=lam, seed=seed, sigmas=sig.numpy(), n_maps=1, n_solves=1, slots=np.asarray([T // 2, T], np.int32),
+               torch_version=torch.__version__, event_bar=event_bar, MU=mean_map.numpy(), SG=std_map.numpy(), goal_0=goal.numpy().astype(np.float32),
+               noise_seed_0=seed, state_0_0=state.numpy(), mean_0_0=mean.numpy(), Ustar_0_0=Ustar.numpy(), Xstar_0_0=Xs[0].numpy(), w_0_0=w.numpy(),
+               cost_0_0=cost.numpy(), Xs_0_0=X_ref[:, [T // 2, T], :].copy(), ev_k_0_0=np.nonzero(ev)[0].astype(np.int32), ev_X_0_0=X_ref[ev].copy())
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:14s} G={G} K={K} T={T} sampled slip: over 1e-4 by mode {counts}, max {worst} -> {os.path.getsize(path)/1024:.0f} KiB")
+    return dict(rollouts=K, over_1e4={str(m): counts[m] for m in counts}, max_dev={str(m): worst[m] for m in worst})
+
+
 def run_census():
     """Stored census fixtures + a larger unstored sweep whose counts go to census_summary.json."""
     import json
     stored = {
         "census_c2": run_census_case("census_c2", G=256, K=1024, T=50, maps=[("smooth", 0), ("smooth", 1), ("iid", 0), ("iid", 1)], n_solves=14),
         "census_c5": run_census_case("census_c5", G=512, K=16384, T=100, maps=[("smooth", 0), ("iid", 0)], n_solves=3),
+        "census_c3": run_census_sampled_case(),
     }
     wide = {
         "c2_wide": run_census_case("c2_wide", G=256, K=1024, T=50, maps=[(k, s) for k in ("smooth", "iid") for s in range(2, 10)], n_solves=40, store=False),
@@ -707,6 +787,8 @@ def main():
         return run_boundary_case()
     if sys.argv[1:] == ["census"]:
         return run_census()
+    if sys.argv[1:] == ["census_c3"]:
+        return run_census_sampled_case()
     if sys.argv[1:] == ["ref5000"]:
         return run_case("ref5000", G=64, res=0.5, K=5000, T=50, risk_mean=smooth_risk_map(64, 9) * 0.7, risk_std=slip_std_map(64, 9),
                         metric="cvar", confidence=0.9, start=[8.0, 8.0, pi / 4], goal=torch.tensor([24, 24]), thr=0.3, n_solves=3,

@@ -221,3 +221,32 @@ def census_classify(fx, key, X):
         assert (pre <= CENSUS_PRE_FLIP_ULP * ulp).all(), f"{key}: rollout {k} is {float((pre / ulp).max()):.1f} ulp off BEFORE its first cell mismatch"
     pos_ulp = (d[..., :2] / np.spacing(np.abs(ref[..., :2]).astype(np.float32))).reshape(d.shape[0], -1).max(1)
     return dict(beyond=beyond, pos_ulp=pos_ulp, theta=d[..., 2].max(1))
+
+
+def census_sampled_draws(seed, K, T):
+    """The slip draws of the census_c3 fixture (make_golden.run_census_sampled_case) in the planner's (K,T) / (K,T+1) / (T)
+    layout: transit draws of step t = portable stream 100 + t, cost draws of slot t = stream 1000 + t, X* draw of step t = 2000 + t."""
+    from oracle import oracle as O
+    zt = np.stack([O.portable_normal(seed, 100 + t, K) for t in range(T)], 1)
+    zc = np.stack([O.portable_normal(seed, 1000 + t, K) for t in range(T + 1)], 1)
+    zo = np.asarray([O.portable_normal(seed, 2000 + t, 1)[0] for t in range(T)], np.float32)
+    return zt, zc, zo
+
+
+def census_tiers(got, fx, key, flipped=()):
+    """cost / w / U* / X* tiers of SURVEY 8a against a census solve (the trajectory tier is census_classify's).  `flipped`:
+    rollouts census_classify found beyond the trajectory tolerance (cell flips): they count as cost outliers, but their cost
+    differs by more than a multiple of the 1e4 collision term -- the trajectory behind it is another one -- so the
+    multiple-of-1e4 residual is taken over the other outliers only."""
+    c_ref = fx[f"cost_{key}"]
+    dc = np.abs(got["cost"] - c_ref)
+    bad = dc > 1e-3 * np.maximum(1.0, np.abs(c_ref))
+    chk = bad.copy()
+    chk[np.asarray(flipped, np.int64)] = False
+    resid = np.abs(dc[chk] - 1e4 * np.round(dc[chk] / 1e4)) if chk.any() else np.zeros(0)
+    return dict(cost_outlier_frac=float(bad.mean()), cost_outlier_resid=float(resid.max()) if resid.size else 0.0,
+                w_max=float(np.abs(got["w"] - fx[f"w_{key}"]).max()), Ustar_max=float(np.abs(got["Ustar"] - fx[f"Ustar_{key}"]).max()),
+                Ustar_rms=float(np.sqrt(np.mean((got["Ustar"] - fx[f"Ustar_{key}"]) ** 2))), Xstar_max=float(np.abs(got["Xstar"] - fx[f"Xstar_{key}"]).max()))
+
+
+TOL_CENSUS = {k: v for k, v in TOL_REF.items() if k not in ("U_max", "X_max")}

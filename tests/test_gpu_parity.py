@@ -277,7 +277,7 @@ def test_errors_are_loud():
         with pytest.raises(BenchnavError):
             pl.controls()                                       # not stored without the flag
     with pytest.raises(BenchnavError, match="LDS"):
-        NativeMPPI(horizon=400, num_samples=64, grid_size=8, resolution=1.0)
+        NativeMPPI(horizon=40000, num_samples=64, grid_size=8, resolution=1.0)      # (horizon=400 takes the slow path: test_gpu_census.py)
 
 
 @pytest.mark.parametrize("K,T,B,sampled", [(4096, 50, 1, False), (2112, 33, 2, False), (16384, 100, 1, False), (8192, 50, 1, True), (2048, 20, 3, True)],
