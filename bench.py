@@ -124,6 +124,34 @@ def host_cpu():
     return {"model": model, "logical_cpus": os.cpu_count(), "physical_cores": len(phys) or None}
 
 
+def pick_device(local, ndev, world, share):
+    """(device ordinal, ranks share a GPU, identities must be checked) for a rank.  Three launch shapes: every rank sees all GPUs
+    (LOCAL_RANK picks); every rank sees exactly one GPU of its own (a launcher that sets ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES
+    per rank: device 0, and the ranks compare identities once the process group is up); a 1-GPU box rehearsing (BENCH_SHARE_GPU)."""
+    if ndev <= 0:
+        return None, False, False
+    if ndev >= world or (local < ndev and ndev > 1):
+        return (local, False, False) if local < ndev else (None, False, False)
+    if share:
+        return local % ndev, True, False
+    if ndev == 1 and world > 1:
+        return 0, False, True                            # EVERY rank of such a launch checks (rank 0 included: the check is a collective)
+    return None, False, False
+
+
+def gpu_identity(torch, dev):
+    pr = torch.cuda.get_device_properties(dev)
+    for key in ("uuid", "pci_bus_id"):
+        v = getattr(pr, key, None)
+        if v is not None:
+            return f"{key}:{v}:{getattr(pr, 'pci_domain_id', '')}:{getattr(pr, 'pci_device_id', '')}"
+    return f"name:{pr.name}:{os.environ.get('ROCR_VISIBLE_DEVICES', '')}:{os.environ.get('HIP_VISIBLE_DEVICES', '')}"
+
+
+def distinct_gpus(ids):
+    return len(set(ids)) == len(ids)
+
+
 def main():
     a = parse()
     if a.gpus < 1:
@@ -157,12 +185,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MPPI planner has no CPU fallback")
     ndev = torch.cuda.device_count()
-    shared_gpu = False
-    if local >= ndev:
-        if not os.environ.get("BENCH_SHARE_GPU"):
-            raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({ndev} visible); one process per GPU needs {world}")
-        shared_gpu = True                              # 1-GPU box rehearsing the N > 1 path (flagged in the output)
-    dev = local % ndev
+    dev, shared_gpu, verify_distinct = pick_device(local, ndev, world, bool(os.environ.get("BENCH_SHARE_GPU")))
+    if dev is None:
+        raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({ndev} visible); one process per GPU needs {world}")
     torch.cuda.set_device(dev)
     dist = None
     # BENCH_FORCE_DIST=1: a single rank goes through the collective path as well (RCCL group of one: init, barrier, device
@@ -179,6 +204,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_dev = torch.device("cuda", dev) if (dist is not None and backend == "nccl") else None
+    if verify_distinct and dist is not None:
+        # every rank sees exactly ONE device (a launcher that sets ROCR_/HIP_VISIBLE_DEVICES per rank): they must be different GPUs
+        ids = [None] * world
+        dist.all_gather_object(ids, gpu_identity(torch, dev))
+        if not distinct_gpus(ids):
+            print(f"rank {rank}: the ranks do not see {world} different GPUs ({ids}); set BENCH_SHARE_GPU=1 to rehearse on a shared one", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(2)                                  # every rank decides the same; no collective is left to hang in
 
     def sync():
         if dist is not None:
@@ -187,7 +220,7 @@ def main():
 
     stream = torch.cuda.current_stream()
     if a.workload != "c2":
-        out = run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev)
+        out = run_workload(a, a.workload, a.steps, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -386,6 +419,15 @@ def main():
         out["lean"] = {"value": 1.0 / s_l, "unit": "solves/s", "ms_per_step": s_l * 1e3,
                        "note": "BN_FLAG_LEAN: _state_seq_batch not materialised; get_top_samples re-rolls the requested rows bit-identically",
                        "roofline": roof(by_l, ms_l, f"rollout_{a.noise}_B1_lean")}
+        # ---- BN_FLAG_REFERENCE_ORDER: the transit in the reference's own operation order (two launches per solve, one stream) ----
+        plo = make_planner(inst, reference_order=True)
+        s_o, ms_o = leg(plo, state_dev, eps_ring, max(300, a.steps))
+        assert plo.arithmetic() == "reference_order"
+        plo.close()
+        out["reference_order"] = {"value": 1.0 / s_o, "unit": "solves/s", "us_per_solve": s_o * 1e6, "launches_per_solve": 2,
+                                  "slowdown_vs_default": s_o / (med / a.steps) if not sustained else s_o / (sustained["ms_per_step"] * 1e-3),
+                                  "note": "same workload with BN_FLAG_REFERENCE_ORDER: sincos of every step's heading and x + ((trav v) cos) dt as "
+                                          "robot_model.py:86-88 writes it (one-wave kernel + stand-alone tail); see parity_census for what it buys"}
         # ---- batched: 64 instances per launch on this GPU (HBM-relevant regime) -------------------
         if not a.no_batched:
             B = a.batched_instances
@@ -490,8 +532,18 @@ def main():
         out["config5_one_gpu"] = {"workload": f"BASELINE configs[4] on one GPU: mppi_solve K={K5} T={T5} map={G5}x{G5}",
                                   "value": 1.0 / s5, "unit": "solves/s", "us_per_solve": s5 * 1e6,
                                   "roofline": roof(bytes5, ms5, f"rollout_K{K5}_T{T5}_G{G5}")}
+    if world > 1 and not a.no_extras:
+        # A multi-GPU run of the DEFAULT command: the two BASELINE configurations that name 8 GPUs ride along as objects of the
+        # same line (configs[3]: 64 instances sharded 64/N per GPU; configs[4]: one K=16384 solve sharded by rollouts), each with
+        # its own roofline and per-rank times -- what `--workload c4|c5` prints as a line of its own.  Every rank takes part.
+        for which in ("c4", "c5"):
+            o = run_workload(a, which, min(a.steps, 50), rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev)
+            if rank == 0:
+                out["sharded_" + which] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "repeats", "scaling", "per_rank_seconds", "config", "roofline")}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds, host_threads)
+    if rank == 0:
+        out["parity_census"] = parity_census()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -499,21 +551,21 @@ def main():
         emit(out)
 
 
-def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev):
+def run_workload(a, which, steps, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev):
     """--workload c4 / c5: the two BASELINE configurations that name 8 GPUs, same contract line (metric, value = whole-job rate,
     barrier + synchronize around exactly K steps, max over ranks), one `roofline` per workload."""
     import numpy as np
     import torch
     from benchnav_amd import NativeMPPI, synth
     from benchnav_amd.sharding import ShardedMPPI, gather_times, shard_instances
-    repeats = max(1, min(50, -(-400 // max(a.steps, 1))))
+    repeats = max(1, min(50, -(-400 // max(steps, 1))))
     names = [None] * world
     me = f"rank {rank}: cuda:{dev} {torch.cuda.get_device_name(dev)}"
     if dist is not None:
         dist.all_gather_object(names, me)
     else:
         names = [me]
-    if a.workload == "c4":
+    if which == "c4":
         total = 64
         mine = shard_instances(total, world, rank)                 # instance ids (= map seeds) of this rank
         B = len(mine)
@@ -533,11 +585,11 @@ def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, 
             pl.sync()
             return dt_
         region(max(a.warmup, 1))
-        walls = [region(a.steps) for _ in range(repeats)]
+        walls = [region(steps) for _ in range(repeats)]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record(stream); pl.solve_n_async_device(max(a.steps, 100), states.data_ptr()); e1.record(stream)
+        torch.cuda.synchronize(); e0.record(stream); pl.solve_n_async_device(max(steps, 100), states.data_ptr()); e1.record(stream)
         pl.flush(); torch.cuda.synchronize(); pl.sync()
-        kernel_ms = e0.elapsed_time(e1) / max(a.steps, 100)
+        kernel_ms = e0.elapsed_time(e1) / max(steps, 100)
         alg = pl.algorithmic_bytes(injected_noise=False) * B
         units_per_step, scaling = total, "strong"          # 64 instances in total whatever N: the total work is fixed
         workload = (f"BASELINE configs[3]: {total} independent 256x256 instances (map seeds 0..{total - 1}), K={K}, T={T}, sharded "
@@ -562,13 +614,13 @@ def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, 
             sh.planner.sync()
             return dt_
         region(max(a.warmup, 1))
-        walls = [region(a.steps) for _ in range(repeats)]
+        walls = [region(steps) for _ in range(repeats)]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record(stream)
-        for _ in range(max(a.steps, 50)):
+        for _ in range(max(steps, 50)):
             sh.solve(st)
         e1.record(stream); torch.cuda.synchronize(); sh.planner.sync()
-        kernel_ms = e0.elapsed_time(e1) / max(a.steps, 50)
+        kernel_ms = e0.elapsed_time(e1) / max(steps, 50)
         # this rank's share of the algorithmic bytes: its rollouts' trajectories and weights, the map, + the exchanged partials
         alg = sh.planner.algorithmic_bytes(injected_noise=False) + 2 * (K5 // 64) * (2 + 2 * T5) * 4
         units_per_step, scaling = 1, "strong"
@@ -581,11 +633,11 @@ def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, 
     job = per_rank.max(dim=0).values
     med = float(job.median())
     r_med = int((job - med).abs().argmin())
-    value = units_per_step * a.steps / med
+    value = units_per_step * steps / med
     if rank != 0:
         return None
-    out = {"metric": "MPPI solve-steps/sec", "value": value, "unit": "solves/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": med / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+    out = {"metric": "MPPI solve-steps/sec", "value": value, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+           "ms_per_step": med / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
            "data": "synthetic", "repeats": repeats, "world_size": world, "devices": names,
            "per_rank_seconds": [float(x) for x in per_rank[:, r_med]], "host_cpu": host_cpu(),
            "collective_backend": (dist.get_backend() if dist is not None else None),
@@ -596,6 +648,31 @@ def run_workload(a, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, 
     if shared_gpu or (dist is not None and backend != "nccl"):
         out["rehearsal"] = f"ranks shared {ndev} GPU(s), backend {backend}: not a scaling measurement"
     return out
+
+
+def parity_census():
+    """What the default arithmetic costs in parity and what BN_FLAG_REFERENCE_ORDER buys back: counts recorded when the census
+    fixtures were captured (tests/golden/make_golden.py census: the imported reference against the three arithmetic modes on the
+    same noise; the HIP kernels are bit-exact with modes 1 and 2, tests/test_gpu_census.py).  Data only -- nothing is computed here."""
+    path = os.path.join(ROOT, "tests", "golden", "census_summary.json")
+    try:
+        s = json.load(open(path))
+    except Exception as e:
+        return {"error": f"{path}: {e}"}
+
+    def rate(recs, trig):
+        n = sum(r["rollouts"] for r in recs)
+        k = sum(r["over_1e4"][trig] for r in recs)
+        return {"rollouts": n, "beyond_1e-4": k, "rate": k / n, "max_dev": max(r["max_dev"][trig] for r in recs)}
+    c2 = [s["stored"]["census_c2"], s["unstored_sweep"]["c2_wide"]]
+    c5 = [s["stored"]["census_c5"], s["unstored_sweep"]["c5_wide"]]
+    return {"tolerance": "max|dX| <= 1e-4 per rollout against the reference (SURVEY 8a (i)); every rollout beyond it is a cell flip "
+                         "(tests/helpers.py census_classify)",
+            "configs[1] K=1024 T=50 G=256": {"default (spec)": rate(c2, "1"), "BN_FLAG_REFERENCE_ORDER": rate(c2, "2"), "libm in reference order": rate(c2, "0")},
+            "configs[4] K=16384 T=100 G=512": {"default (spec)": rate(c5, "1"), "BN_FLAG_REFERENCE_ORDER": rate(c5, "2"), "libm in reference order": rate(c5, "0")},
+            "configs[2] K=8192 T=50 sampled slip": {"default (spec)": s["stored"]["census_c3"]["over_1e4"]["1"], "BN_FLAG_REFERENCE_ORDER": s["stored"]["census_c3"]["over_1e4"]["2"],
+                                                    "rollouts": s["stored"]["census_c3"]["rollouts"]},
+            "source": "tests/golden/census_summary.json (torch " + str(s.get("torch_version")) + ")"}
 
 
 def rehearse(rank, world, local, backend):

@@ -97,6 +97,11 @@ class MPPI(nn.Module):
                       block); False returns views of the planner's buffers (overwritten by the next call).
       lean            do not materialise `_state_seq_batch` (70 % of a solve's HBM bytes): get_top_samples re-rolls the
                       winners on demand and `_state_seq_batch` re-rolls all K rows when it is read, bit-identical either way.
+      reference_order the transit in the reference's own operation order (robot_model.py:86-88: sin / cos of every step's
+                      heading, x + ((trav v) cos) dt): no cell flips against the reference beyond what libm vs SLEEF gives
+                      (DESIGN.md 5), at ~4x the latency (two launches per solve).  The default arithmetic leaves about one
+                      rollout in 30 000 (T = 50) in a neighbouring cell.  `arithmetic` tells which one a planner runs; a
+                      `delta_t * max|omega|` above 0.5 rad selects the reference order by itself.
 
     Streams: the planner enqueues on the torch stream that was current for its device at construction.  forward() called
     under another current stream fences the two with events (correct, slower); keep one stream for the best latency.
@@ -106,7 +111,7 @@ class MPPI(nn.Module):
                  sigmas: torch.Tensor, lambda_: float, device=torch.device("cuda"), dtype=torch.float32,
                  seed: int = 42, *, noise: str = "torch_device", store_controls: bool = True,
                  copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1, sampled_slip: bool = False,
-                 lean: bool = False) -> None:
+                 lean: bool = False, reference_order: bool = False) -> None:
         super().__init__()
         torch.manual_seed(seed)                                    # mppi.py:55
 
@@ -164,7 +169,8 @@ class MPPI(nn.Module):
         cfg.lambda_, cfg.dt, cfg.stuck_threshold = lambda_, delta_t, inp["stuck_threshold"]
         cfg.seed = seed
         cfg.flags = ((_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0) | (_capi.BN_FLAG_PROFILE if profile else 0)
-                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0) | (_capi.BN_FLAG_LEAN if lean else 0))
+                     | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0) | (_capi.BN_FLAG_LEAN if lean else 0)
+                     | (_capi.BN_FLAG_REFERENCE_ORDER if reference_order else 0))
         self._lean = bool(lean)
         with torch.cuda.device(dev):
             self._stream = torch.cuda.current_stream(dev)
@@ -224,6 +230,11 @@ class MPPI(nn.Module):
                 h.value = None
         except Exception:
             pass
+
+    @property
+    def arithmetic(self) -> str:
+        """'spec' (default: carried heading vector, fused transit) or 'reference_order' (robot_model.py:86-88 as written)."""
+        return "reference_order" if self._lib.bn_mppi_arithmetic(self._handle) == 1 else "spec"
 
     def set_risk_map(self, risks: torch.Tensor) -> None:
         """Replace the risk map (dynamics._traversability_model._risks, (G,G) [iy,ix])."""

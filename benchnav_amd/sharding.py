@@ -116,6 +116,16 @@ class ShardedMPPI:
         self._counts = [shard_rollouts(num_samples, self.world, r)[1] // 64 for r in range(self.world)]
         self._gathered = torch.empty(sum(self._counts), 2 + 2 * horizon, dtype=torch.float32, device=self.device)
         self._host_backend = bool(self._dist) and self._dist.get_backend(group) != "nccl"
+        # Exchange buffers, allocated ONCE (round 3 made a zeros + an empty per solve in the hot loop).  Equal shards on RCCL -- the
+        # normal case, K a multiple of 64 x world -- need none: the collective gathers this rank's partial rows straight out of planner
+        # memory into `_gathered`, which the tail reads.  Ragged shards are padded to the largest; the gloo rehearsal stages on the host.
+        maxc, PS = max(self._counts), 2 + 2 * horizon
+        self._direct = (not self._host_backend) and min(self._counts) == maxc
+        if self._dist is not None and not self._direct:
+            where = "cpu" if self._host_backend else self.device
+            self._send = torch.zeros(maxc, PS, dtype=torch.float32, device=where)
+            self._recv = torch.empty(self.world * maxc, PS, dtype=torch.float32, device=where)
+        self._views = {}                                 # partial rows of the planner's per-solve slots, wrapped once each
 
     def _view(self, ptr, shape):
         from .mppi import _DevArray
@@ -123,10 +133,14 @@ class ShardedMPPI:
 
     def _partials_tensor(self):
         ptr, n, ps = self.planner.shard_partials()
-        return self._view(ptr, (n, ps))
+        v = self._views.get(ptr)
+        if v is None:
+            v = self._views[ptr] = self._view(ptr, (n, ps))
+        return v
 
     def solve(self, state_dev: torch.Tensor, eps_dev: Optional[torch.Tensor] = None, kind: Optional[int] = None):
-        """state_dev: (3,) float32 on the GPU; eps_dev: this rank's slice of the noise or None (Philox in-kernel)."""
+        """state_dev: (3,) float32 on the GPU; eps_dev: this rank's slice of the noise or None (Philox in-kernel).
+        Three stream-ordered steps, nothing allocated: rollouts of the shard, all-gather of the partial rows, merge + tail."""
         from . import _capi
         if eps_dev is None:
             self.planner.shard_rollout_async_device(state_dev.data_ptr())
@@ -135,19 +149,17 @@ class ShardedMPPI:
         mine = self._partials_tensor()
         if self._dist is None:                           # no process group: one rank, nothing to exchange
             self._gathered.copy_(mine)
+        elif self._direct:
+            self._dist.all_gather_into_tensor(self._gathered, mine, group=self.group)      # RCCL over xGMI with backend "nccl"
         else:
-            # equal-sized all-gather (ragged shards are padded to the largest), then the valid rows in rank order
-            maxc = max(self._counts)
-            host = self._host_backend                    # gloo rehearsal: stage through the host
-            send = torch.zeros(maxc, mine.shape[1], dtype=torch.float32, device="cpu" if host else self.device)
-            send[:mine.shape[0]].copy_(mine)
-            recv = torch.empty(self.world * maxc, mine.shape[1], dtype=torch.float32, device=send.device)
-            self._dist.all_gather_into_tensor(recv, send, group=self.group)      # RCCL over xGMI with backend "nccl"
-            recv = recv.view(self.world, maxc, -1)
-            if min(self._counts) == maxc:
-                self._gathered.copy_(recv.reshape(-1, mine.shape[1]))
-            else:
-                self._gathered.copy_(torch.cat([recv[r, :c] for r, c in enumerate(self._counts)]))
+            self._send[:mine.shape[0]].copy_(mine)
+            self._dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+            maxc = self._send.shape[0]
+            recv = self._recv.view(self.world, maxc, -1)
+            row = 0
+            for r, c in enumerate(self._counts):         # the valid rows in rank order
+                self._gathered[row:row + c].copy_(recv[r, :c])
+                row += c
         self.planner.shard_finish_async(self._gathered.data_ptr(), self._gathered.shape[0])
         return self
 

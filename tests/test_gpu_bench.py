@@ -44,6 +44,27 @@ def test_gpus_2_self_launches_two_ranks_on_the_device():
     if share:
         assert "rehearsal" in out
     assert out["value"] > 10000
+    # a multi-GPU run of the DEFAULT command carries the two BASELINE workloads that name 8 GPUs as objects of the same line
+    for key, cfg in (("sharded_c4", "configs[3]"), ("sharded_c5", "configs[4]")):
+        o = out[key]
+        assert cfg in o["config"]["workload"] and o["scaling"] == "strong" and len(o["per_rank_seconds"]) == 2
+        assert 0 < o["roofline"]["frac"] < 1 and o["value"] > 1000
+    assert out["parity_census"]["configs[1] K=1024 T=50 G=256"]["BN_FLAG_REFERENCE_ORDER"]["beyond_1e-4"] == 0
+
+
+def test_ranks_that_each_see_one_device_must_see_different_ones():
+    """A launcher that gives every rank ONE visible device (LOCAL_RANK >= device_count): device 0 is taken and the ranks compare GPU
+    identities once the group is up.  On this box both ranks see the same GPU: a clear refusal, not a silent double booking."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box where every rank sees exactly one device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SHARE_GPU")}
+    env["BENCH_DIST_BACKEND"] = "gloo"
+    port = 29000 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "do not see 2 different GPUs" in r.stderr, r.stderr[-2000:]
 
 
 def test_a_single_rank_goes_through_rccl_when_asked():

@@ -202,3 +202,23 @@ def test_reference_order_serves_every_noise_source_and_the_lean_reroll():
                 pl.solve_async_device(sd.data_ptr(), ed.data_ptr(), kind)
                 pl.sync()
                 assert np.array_equal(pl.states(), orc1["X"]) and np.array_equal(pl.costs(), orc1["cost"])
+
+
+def test_drop_in_class_in_reference_order():
+    """benchnav_amd.MPPI(reference_order=True) on the c1 fixture (BASELINE configs[0], the reference's own noise): the arithmetic
+    the class reports, and every rollout within the UN-tiered trajectory tolerance of the reference, no cost outlier."""
+    import torch
+    from helpers import TOL_REF, mppi_for_fixture, parity_metrics
+    fx = load_case("c1_basic")
+    solver = mppi_for_fixture(fx, noise="torch", reference_order=True)
+    assert solver.arithmetic == "reference_order"
+    assert mppi_for_fixture(fx, noise="torch").arithmetic == "spec"
+    for i in range(int(fx["n_solves"])):
+        solver._previous_action_seq = torch.from_numpy(fx[f"mean_{i}"])
+        with torch.no_grad():
+            U, X = solver.solve_with_noise(torch.tensor(fx[f"state_{i}"]), torch.from_numpy(fx[f"eps_{i}"]))
+        got = dict(U=solver._perturbed_action_seqs.cpu().numpy(), X=solver._state_seq_batch.cpu().numpy(), cost=solver._costs.cpu().numpy(),
+                   w=solver._weights.cpu().numpy(), Ustar=U.cpu().numpy(), Xstar=X[0].cpu().numpy())
+        m = parity_metrics(got, fx, i)
+        assert_within(m, TOL_REF, ctx=f"c1_basic solve {i} reference order")
+        assert m["cost_outliers"] == 0 and m["X_max"] <= 1e-5

@@ -56,3 +56,21 @@ def test_mppi_constructor_asserts_like_the_reference():
     Dyn.min_action = torch.tensor([0.0, -1.0])
     with pytest.raises(AssertionError, match="sigmas"):
         MPPI(5, 8, 3, 2, Dyn(), object(), torch.tensor([0.5]), 0.5)
+
+
+def test_bench_device_mapping_and_census_object():
+    """bench.py's rank -> device rule for the three launch shapes, and the parity_census object it prints (data from the fixtures)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.pick_device(3, 8, 8, False) == (3, False, False)            # every rank sees all GPUs
+    assert bench.pick_device(3, 1, 8, False) == (0, False, True)             # every rank sees one: device 0, identities checked later
+    assert bench.pick_device(0, 1, 8, False) == (0, False, True)             # ... by rank 0 as well: the check is a collective
+    assert bench.pick_device(0, 1, 1, False) == (0, False, False)
+    assert bench.pick_device(3, 1, 8, True) == (0, True, False)              # rehearsal on a shared GPU
+    assert bench.pick_device(9, 8, 16, False)[0] is None and bench.pick_device(0, 0, 1, False)[0] is None
+    assert bench.distinct_gpus(["a", "b"]) and not bench.distinct_gpus(["a", "a"])
+    pc = bench.parity_census()
+    c2, c5 = pc["configs[1] K=1024 T=50 G=256"], pc["configs[4] K=16384 T=100 G=512"]
+    assert c2["default (spec)"]["rollouts"] >= 5e5 and 0 < c2["default (spec)"]["rate"] < 1.2e-4 and c2["BN_FLAG_REFERENCE_ORDER"]["rate"] < 3e-5
+    assert 0 < c5["default (spec)"]["rate"] < 4e-4 and c5["BN_FLAG_REFERENCE_ORDER"]["rate"] < 3e-5
