@@ -91,6 +91,7 @@ SYMBOLS = {
     "bn_mppi_solve_count": (C.c_uint64, [_H]),
     "bn_mppi_arithmetic": (C.c_int32, [_H]),
     "bn_mppi_launches_per_solve": (C.c_int32, [_H]),
+    "bn_mppi_fast_quotient": (C.c_int32, [_H]),
     "bn_mppi_row_pitch": (C.c_int32, [_H]),
     "bn_mppi_kernel_ms": (C.c_int, [_H, _FP, _FP, C.POINTER(C.c_int32)]),
     "bn_mppi_algorithmic_bytes": (C.c_int64, [_H, C.c_int]),

@@ -41,6 +41,14 @@ bool wave_kernel_is_faster(const bn::SolveParams &p, size_t resident_role_wgs, i
 }
 thread_local std::string g_last_error;
 
+// Experiment switches (environment variables read by the measurement tools under tools/): compiled in only with -DBN_EXPERIMENTS
+// (tools/build_variant*.py pass it); the shipped library has none in its entry points.
+#ifdef BN_EXPERIMENTS
+inline const char *exp_env(const char *name) { return std::getenv(name); }
+#else
+inline const char *exp_env(const char *) { return nullptr; }
+#endif
+
 int fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -478,7 +486,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     // 60: 28.5 vs 24.9): the dispatcher then fills the CUs unevenly (3 to 5 workgroups per CU instead of 4, tools/block_trace.py)
     // and a few workgroups wait for a second round.  Default: instance per grid row, workgroups of an instance spread over the XCDs.
     p.xs = 0;
-    if (const char *e = std::getenv("BN_XCD_PACK")) p.xs = (e[0] == '1') ? 3 : 0;      // experiments (tools/r2_measure.py)
+    if (const char *e = exp_env("BN_XCD_PACK")) p.xs = (e[0] == '1') ? 3 : 0;      // experiments (tools/r2_measure.py)
 
     h->n_maps = (cfg->flags & BN_FLAG_SHARED_MAP) ? 1 : p.B;
     p.map_stride = (h->n_maps == 1) ? 0 : p.G * p.G;
@@ -583,7 +591,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     // 13.9) --, its LDS layout must fit, not forced elsewhere
     h->lat_kernel = h->pipelined && !h->wave_kernel && !(cfg->flags & BN_FLAG_ROLE_KERNEL) && bn::lat_lds_bytes(p) > 0 &&
                     ((cfg->flags & BN_FLAG_LAT_KERNEL) || ((size_t)p.B + 1) * (p.nblk + 1) <= (size_t)std::max(prop.multiProcessorCount, 1));
-    if (const char *e = std::getenv("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
+    if (const char *e = exp_env("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
     alloc(&h->d_flags, ((kSlots + 1) * B + 2) * bn::kFlagStride * sizeof(unsigned long long));
     alloc(&h->d_mean_snap, B * T * 2 * 4);
     if (rc == BN_OK) {
@@ -597,23 +605,23 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         else std::memset(h->h_mail, 0, B * 2 * sizeof(unsigned long long));
     }
     p.mail = h->d_mail;
-    if (h->lat_kernel && p.nblk <= 16 && 2 * p.T <= bn::kRolloutThreads && !std::getenv("BN_NO_GRANULES"))
+    if (h->lat_kernel && p.nblk <= 16 && 2 * p.T <= bn::kRolloutThreads && !exp_env("BN_NO_GRANULES"))
         for (int q = 0; q < kSlots; ++q) alloc(&h->d_gran[q], (B * (size_t)p.nblk * (2 + 2 * T) + 4 * B) * sizeof(unsigned long long));   // rows, then 4 per instance for the state
     // the role kernel (launches that do not leave every workgroup a CU of its own) overlaps its launches as well: a workgroup of
     // the next solve takes the slot a finished one frees and waits there for ITS instance's previous solve only
     h->role_overlap = h->pipelined && !h->lat_kernel && !(cfg->flags & BN_FLAG_NO_OVERLAP);
-    if (const char *e = std::getenv("BN_ROLE_OVERLAP")) h->role_overlap = h->role_overlap && e[0] != '0';   // experiments
+    if (const char *e = exp_env("BN_ROLE_OVERLAP")) h->role_overlap = h->role_overlap && e[0] != '0';   // experiments
     // the deterministic kernel's ticket path (K > 4096: one launch per solve, merge by the last workgroup) overlaps its launches as well
     const bool ticket_det = !h->slow_path && !p.slip_on && !h->pipelined && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= 1024 &&
                             bn::finish_lds_bytes(p) + 256 <= bn::rollout_lds_bytes(p);
     h->ticket_overlap = (ticket_det || (!(cfg->flags & BN_FLAG_NO_PIPELINE) && bn::sampled_fused(p))) && !(cfg->flags & BN_FLAG_NO_OVERLAP) &&
-                        !std::getenv("BN_NO_TICKET_OVERLAP");
+                        !exp_env("BN_NO_TICKET_OVERLAP");
     const bool may_overlap = (h->lat_kernel || h->role_overlap || h->ticket_overlap) && !(cfg->flags & BN_FLAG_NO_OVERLAP);
     if (may_overlap) {
         // Two launches in flight.  Measured with three (role kernel, 64 instances): 23.3 instead of 22.6 us per launch; with
         // four the launches starve each other of slots (waits expire).  The slot / buffer arithmetic below holds for up to kMaxStreams.
         h->n_streams = 2;
-        if (const char *e = std::getenv("BN_OVERLAP_STREAMS")) h->n_streams = std::min(std::max(std::atoi(e), 2), kMaxStreams);   // experiments
+        if (const char *e = exp_env("BN_OVERLAP_STREAMS")) h->n_streams = std::min(std::max(std::atoi(e), 2), kMaxStreams);   // experiments
         for (int q = 0; q + 1 < h->n_streams; ++q) {
             if (h->d_X) alloc(&h->d_Xalt[q], B * (T + 1) * 3 * (size_t)p.Kp * 4);
             if (h->d_U) alloc(&h->d_Ualt[q], B * T * 2 * (size_t)p.Kp * 4);
@@ -648,6 +656,25 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         alloc(&h->d_gpart, (size_t)p.B * 64 * (2 + 2 * p.T) * 4);
         p.gpart = h->d_gpart;
         h->ticket_mode = true;             // p.ticket stays null in h->p: only the one-launch path selects the ticket kernel
+    }
+    if (rc == BN_OK && !p.pow2) {
+        // general resolution: the in-loop lookups divide with the three-instruction quotient (quotient_general); check it over every
+        // float they can see -- ~1e9 values, a millisecond -- before anything relies on it
+        unsigned long long *bad = h->d_flags + ((kSlots + 1) * B + 1) * bn::kFlagStride;      // the spare counter slot, zero
+        const float d_max = std::max(p.x_hi - p.x0, p.y_hi - p.y0);
+        unsigned long long n_bad = 1;
+        if (!(std::isfinite(d_max) && d_max >= 0.0f) || bn::launch_quotient_check(p.res, p.inv_res, d_max, bad, nullptr) != hipSuccess ||
+            hipMemcpy(&n_bad, bad, sizeof n_bad, hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(BN_ERR_HIP, "checking the cell-index quotient for resolution %g failed", (double)p.res);
+        } else if (n_bad != 0) {
+            rc = fail(BN_ERR_INVALID, "resolution %.9g: the correctly rounded three-instruction quotient disagrees with the division for %llu "
+                                      "positions in [0, %g] (no such resolution was known: please report it); use a neighbouring value",
+                      (double)p.res, n_bad, (double)d_max);
+        } else {
+            p.fast_div = 1;
+        }
+        (void)hipMemset(bad, 0, sizeof n_bad);
     }
     if (rc == BN_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(BN_ERR_HIP, "hipDeviceSynchronize failed after allocation");
     // Overlapped launches need an extra stream that DISPATCHES concurrently with the handle's stream.  HIP deals its streams onto a
@@ -1169,8 +1196,8 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // The last launch of a long batch can carry its own tail as a second aux workgroup (SolveParams::self_tail) instead of a tail
     // kernel behind it.  Measured (tools/region_overhead.py, K = 20): 0.7 us better with round 2's kernel, 5 us WORSE since the
     // barrier-free prologue (225.2 vs 230.2 us) -- off unless BN_SELF_TAIL is set; the code stays for the next look at the region's ends.
-    static const bool exp_self_tail = std::getenv("BN_SELF_TAIL") != nullptr;
-    static const bool exp_align = std::getenv("BN_NO_ALIGN") == nullptr;
+    static const bool exp_self_tail = exp_env("BN_SELF_TAIL") != nullptr;
+    static const bool exp_align = exp_env("BN_NO_ALIGN") == nullptr;
     if (!exp_align) idle = false;                                   // (only the stream assignment below looks at it from here on)
     int rc = BN_OK;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
@@ -1190,7 +1217,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // (flush, sync, a getter) would sit behind the join's barrier packet, ~10 us of queue processing after the last rollout kernel.
     // Short batches keep the tail pending: chained short batches carry it in their next launch for free.
     if (rc == BN_OK && n >= kEagerTailMinBatch && !h->in_episode) rc = flush_tail(h);
-    static const bool exp_join = std::getenv("BN_JOIN") != nullptr;   // experiments (tools/region_overhead.py)
+    static const bool exp_join = exp_env("BN_JOIN") != nullptr;   // experiments (tools/region_overhead.py)
     for (int q = 0; exp_join && q + 1 < S; ++q) {                   // join: the handle's stream continues behind all of them
         hipError_t e1 = hipEventRecord(h->ev_join[q], h->xstream[q]);
         hipError_t e2 = hipStreamWaitEvent(h->stream, h->ev_join[q], 0);
@@ -1223,7 +1250,7 @@ int bn_mppi_env_attach(bn_mppi_t *h, const float *latent_mean, const float *late
     h->p.goal_thr = goal_threshold; h->p.env_dt = delta_t; h->p.env_seed = seed;
     // latency kernel, overlapped episodes: how far one environment step can move the start cell (see SolveParams::spec_extra)
     h->p.spec_extra = 0;
-    if (h->lat_kernel && h->d_gran[0] && !std::getenv("BN_NO_SPEC_WINDOW")) {
+    if (h->lat_kernel && h->d_gran[0] && !exp_env("BN_NO_SPEC_WINDOW")) {
         const double vmax = std::max(std::fabs((double)h->p.umin0), std::fabs((double)h->p.umax0));
         const double cells = std::floor(vmax * (double)delta_t / (double)h->p.res) + 1.0;
         if (cells <= 8.0 && h->p.WN + 2 * (int)cells <= h->p.G + 1) {
@@ -1685,6 +1712,7 @@ int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size
 uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves : 0; }
 
 int32_t bn_mppi_arithmetic(const bn_mppi_t *h) { return h ? h->p.ref_order : -1; }
+int32_t bn_mppi_fast_quotient(const bn_mppi_t *h) { return h ? (h->p.pow2 ? 2 : h->p.fast_div) : -1; }
 int32_t bn_mppi_launches_per_solve(const bn_mppi_t *h) { return h ? ((h->pipelined || h->ticket_mode) ? 1 : 2) : -1; }
 
 int32_t bn_mppi_row_pitch(const bn_mppi_t *h) { return h ? h->p.Kp : 0; }

@@ -107,6 +107,22 @@ __device__ __forceinline__ int raw_cell(float v, float origin, float res, float 
     return (int)floorf(q);                    // v_cvt_i32_f32 saturates
 }
 
+// (p - origin) / res for a resolution that is not a power of two, as the reference rounds it (a true division, grid_map.py:203), for
+// the in-loop lookups: d >= 0 is a clamped position minus the lower limit.  With r = RN(1 / res) (the host's correctly rounded
+// reciprocal) q0 = d r, e = fma(-q0, res, d) (the exact residual), q = fma(e, r, q0) is the correctly rounded quotient (Markstein's
+// correction step): three packed instructions where the IEEE expansion of two divisions is twenty-two.  No branch back to the
+// division here (it cost the chain 1.4 us per solve, tools/res_rate.py): bn_mppi_create checks the form EXHAUSTIVELY on the device
+// -- every float d in [0, upper limit - lower limit]: same floor as d / res, same bits above the denormal range -- and refuses a
+// resolution that fails (none known: a host sweep over resolutions incl. all-ones significands, the theorem's exception, found no
+// mismatch above 1e-30).  K=1024, T=50 at res 0.3: 13.1 (division) -> 10.0 us per solve; res 0.5 (exact multiply): 8.7.
+__device__ __forceinline__ v2f quotient_general(const SolveParams &p, v2f d)
+{
+    const v2f r = {p.inv_res, p.inv_res}, b = {p.res, p.res};
+    const v2f q0 = d * r;
+    const v2f e = __builtin_elementwise_fma(-q0, b, d);
+    return __builtin_elementwise_fma(e, r, q0);
+}
+
 // Window of edge wn covering `reach` cells either side of the cell of (sx, sy) and one more above, shifted into the map PLUS ONE
 // GUARD ROW / COLUMN at index G (staged as a copy of row / column G-1): a position on the upper map limit has the raw cell G, and
 // the reference's index clamp (grid_map.py:209) is then built into the window instead of costing the chain two clamps a step.
@@ -151,8 +167,14 @@ template <int GEO, bool LDSWIN, bool SAFE>
 __device__ __forceinline__ float trav_lookup(const SolveParams &p, const float *win,
                                              const float *__restrict__ map, const Win w, float x, float y)
 {
-    int ix = raw_cell<GEO>(x, p.x0, p.res, p.inv_res);
-    int iy = raw_cell<GEO>(y, p.y0, p.res, p.inv_res);
+    int ix, iy;
+    if (GEO == kGeoGeneral && !SAFE) {                 // in-loop lookup of a clamped position: the validated three-instruction quotient
+        const v2f q = quotient_general(p, v2f{x, y} - v2f{p.x0, p.y0});
+        ix = (int)floorf(q.x); iy = (int)floorf(q.y);
+    } else {
+        ix = raw_cell<GEO>(x, p.x0, p.res, p.inv_res);
+        iy = raw_cell<GEO>(y, p.y0, p.res, p.inv_res);
+    }
     if (LDSWIN) {
         if (SAFE) { ix = clampi(ix, 0, p.G - 1); iy = clampi(iy, 0, p.G - 1); }
         const int li = clampi(ix - w.wx0, 0, p.WN - 1);
@@ -180,7 +202,7 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
     } else if (GEO == kGeoPow2) {
         q = __builtin_elementwise_fma(xy - v2f{p.x0, p.y0}, ir, nw);
     } else {
-        q = v2f{(x - p.x0) / p.res, (y - p.y0) / p.res} + nw;
+        q = quotient_general(p, xy - v2f{p.x0, p.y0}) + nw;
     }
     if (ASMIDX == 1) {
         // The latency kernel's chain wave: floor-and-convert in one instruction, row * WN + col as one v_mad_u32_u24 (left to itself
@@ -356,7 +378,7 @@ __device__ __forceinline__ int slip_cell_window(const SolveParams &p, const Win 
     const v2f xy = {x, y}, ir = {p.inv_res, p.inv_res}, nw = {-w.fx0, -w.fy0};
     if (GEO == kGeoPow2Origin0) q = __builtin_elementwise_fma(xy, ir, nw);
     else if (GEO == kGeoPow2) q = __builtin_elementwise_fma(xy - v2f{p.x0, p.y0}, ir, nw);
-    else q = v2f{(x - p.x0) / p.res, (y - p.y0) / p.res} + nw;
+    else q = quotient_general(p, xy - v2f{p.x0, p.y0}) + nw;
     const float li = clampf(floorf(q.x), 0.0f, w.fwm1);
     const float lj = clampf(floorf(q.y), 0.0f, w.fwm1);
     return (int)__builtin_fmaf(lj, w.fwn, li);

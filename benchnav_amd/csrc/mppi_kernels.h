@@ -29,6 +29,8 @@ struct SolveParams {
                          // staged this much wider around the PREVIOUS state while the new one is not known yet; 0 = stage afterwards
     int map_stride;      // G*G if every instance has its own map, 0 if shared
     int pow2;            // resolution is a power of two
+    int fast_div;        // general resolution: the in-loop quotient (p - origin) / res (Markstein's three-instruction form, quotient_general
+                         // in mppi_device.h) passed the exhaustive check at create
     int store_u;
     int wave_kernel;     // launch the one-wave-per-64-rollouts throughput variant (many workgroups per launch)
     int lat_kernel;      // launch the barrier-free latency variant of the role kernel (every workgroup has a CU to itself)
@@ -165,6 +167,8 @@ hipError_t launch_env_collision(const SolveParams &p, const float *states, int N
 // flag_and_seen: two zeroed device ints.  A grid on `waiter` that the chip cannot hold at once stays until a kernel on `setter` has
 // set the flag (bounded) and records in [1] whether its first workgroup saw it: only if the two streams dispatch concurrently.
 hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter, int n_cus);
+// every float d in [0, d_max]: does quotient_general's fast form give floor(d / res) (and the same bits for d >= 1e-30)?  *bad = count of failures
+hipError_t launch_quotient_check(float res, float inv_res, float d_max, unsigned long long *bad, hipStream_t s);
 hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipStream_t s);   // 0 sqrt, 1 sin, 2 cos, 3 wrap, 4 wrap_near
 
 // layout conversion helpers (planner-native k-fastest <-> reference k-major)

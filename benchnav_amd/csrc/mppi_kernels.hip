@@ -20,6 +20,7 @@
 // live in rollout_role_*.hip (five-wave role split, one file per noise source), rollout_wave.hip (throughput
 // variant) and rollout_sampled.hip (config 3); the device code they share is mppi_device.h.
 #include "mppi_device.h"
+#include <cstring>
 
 namespace bn {
 
@@ -532,6 +533,28 @@ hipError_t launch_env_collision(const SolveParams &p, const float *states, int N
     case kGeoPow2: env_collision_kernel<kGeoPow2><<<grid, 256, 0, s>>>(p, states, N, thr, z, draw, out); break;
     default: env_collision_kernel<kGeoGeneral><<<grid, 256, 0, s>>>(p, states, N, thr, z, draw, out); break;
     }
+    return hipGetLastError();
+}
+
+__global__ void quotient_check_kernel(float res, float inv_res, uint32_t last, unsigned long long *bad)
+{
+    SolveParams p{};
+    p.res = res; p.inv_res = inv_res;
+    unsigned long long mine = 0;
+    for (uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u <= last; u += (uint64_t)gridDim.x * blockDim.x) {
+        const float d = __uint_as_float((uint32_t)u);
+        const v2f q = quotient_general(p, v2f{d, d});
+        const float t = d / res;
+        if (floorf(q.x) != floorf(t) || (d >= 1.0e-30f && q.x != t) || q.y != q.x) ++mine;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+hipError_t launch_quotient_check(float res, float inv_res, float d_max, unsigned long long *bad, hipStream_t s)
+{
+    uint32_t last;
+    std::memcpy(&last, &d_max, 4);                      // non-negative floats order like their bit patterns
+    quotient_check_kernel<<<4096, 256, 0, s>>>(res, inv_res, last, bad);
     return hipGetLastError();
 }
 

@@ -301,6 +301,10 @@ class NativeMPPI:
         """'spec' (carried heading vector, fused transit: the default) or 'reference_order' (robot_model.py:86-88 as written)."""
         return "reference_order" if self._lib.bn_mppi_arithmetic(self._h) == 1 else "spec"
 
+    def fast_quotient(self) -> int:
+        """2: power-of-two resolution (exact multiply); 1: the three-instruction quotient, validated exhaustively at create."""
+        return int(self._lib.bn_mppi_fast_quotient(self._h))
+
     def launches_per_solve(self) -> int:
         return int(self._lib.bn_mppi_launches_per_solve(self._h))
 

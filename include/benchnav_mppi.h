@@ -188,19 +188,24 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
                           float *out_device);
 /* n dependent solves enqueued from one call (the warm start chains them on the device; the state is
  * re-read from `states` by every solve).  Noise block i is eps + (i % eps_ring) * eps_stride floats.
- * With the latency kernel (small launches) and n >= 3 the solves alternate between the handle's stream and an
- * internal one and overlap: solve i+1 is dispatched while solve i runs and waits on a device counter for its
- * partials instead of for its kernel's end; the call forks from and joins back into the handle's stream, so the
- * caller sees ordinary stream order, and the results are bit-identical (BN_FLAG_NO_OVERLAP turns it off).
+ * With n >= 3 (and device-resident inputs) the solves of one call alternate between the handle's stream and an internal one and
+ * OVERLAP: solve i+1 is dispatched while solve i runs and waits on the device for its predecessor's softmin partials instead of
+ * for its kernel's end; results are bit-identical to the one-stream chain (BN_FLAG_NO_OVERLAP turns it off: the switch for a GPU
+ * shared with other work).  What is ordered for the caller:
+ *   - the LAST solve of the call and the tail behind it run on the handle's stream, so work enqueued there afterwards is ordered
+ *     behind the batch's final results by the queue itself; the internal stream is not joined back -- its kernels have handed
+ *     everything over through device counters by then and end within microseconds (bn_mppi_sync waits for both);
+ *   - `states` and `eps` are read by every solve of the call: they must stay valid AND UNCHANGED until the synchronisation point
+ *     that follows the batch (bn_mppi_sync, a getter, or the caller's own stream synchronisation), as for any asynchronous call.
  * Device-side waits are bounded (~2 s: another user of the GPU kept a predecessor from becoming resident).  If one expires the
  * launch computes on incomplete partials; the error word it sets lives in pinned host memory and is looked at by EVERY entry
  * point that synchronises (bn_mppi_sync, the getters, the setters, bn_mppi_episode_log ...) and by bn_mppi_flush: the batches
  * enqueued since the last clean synchronisation point are then RE-RUN on one stream from the mean the first of them started
- * from (kept on the device), with the same Philox positions and the callers' state / noise buffers -- which therefore must stay
- * valid and unchanged until the synchronisation point that follows a batch.  The call returns BN_OK with a warning in
- * bn_last_error(), bn_mppi_recovery_count() counts these events (consumers enqueued in stream order BEFORE the
- * synchronisation point have read invalid buffers), and the handle keeps to one stream from then on.  BN_ERR_HIP only when the
- * batches cannot be re-run (host-resident inputs, more than 4096 batches without a synchronising call). */
+ * from (kept on the device), with the same Philox positions and the callers' state / noise buffers -- the second reason for the
+ * "unchanged" rule above: a caller that rewrote its state tensor in place between batches gets the re-run on the NEW contents.
+ * The call returns BN_OK with a warning in bn_last_error(), bn_mppi_recovery_count() counts these events (consumers enqueued in
+ * stream order BEFORE the synchronisation point have read invalid buffers), and the handle keeps to one stream from then on.
+ * BN_ERR_HIP only when the batches cannot be re-run (host-resident inputs, more than 4096 batches without a synchronising call). */
 int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
 
@@ -339,6 +344,10 @@ uint64_t bn_mppi_solve_count(const bn_mppi_t *h);
  * (BN_FLAG_REFERENCE_ORDER, or selected because dt * max|omega| > 0.5).  Kernel launches one solve costs: 1 or 2. */
 int32_t bn_mppi_arithmetic(const bn_mppi_t *h);
 int32_t bn_mppi_launches_per_solve(const bn_mppi_t *h);
+/* How the cell index divides by the resolution (grid_map.py:203): 2 = exact multiplication (power-of-two resolution), 1 = the
+ * three-instruction correctly rounded quotient, validated exhaustively on the device at create for this resolution and these limits
+ * (bn_mppi_create refuses a resolution that fails the check; none is known). */
+int32_t bn_mppi_fast_quotient(const bn_mppi_t *h);
 
 /* With BN_FLAG_PROFILE: mean duration in milliseconds of the rollout kernel and of
  * the finish kernel over the solves since the last call (HIP events on the

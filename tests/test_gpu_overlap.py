@@ -135,6 +135,26 @@ def test_overlapped_episodes_log_the_same_closed_loop(K, T, B, n, corner):
             assert np.array_equal(x, y), (b, j)
 
 
+def test_speculative_window_on_a_map_it_fills_exactly():
+    """Closed loop, latency kernel, overlapped: the successor stages a window one environment step wider around the PREVIOUS state
+    (spec_extra cells each side).  On a 24 x 24 map that window is the whole map plus the guard row / column (WN + 2 spec_extra =
+    25 = G + 1, the largest bn_mppi_env_attach admits): rovers in both corners, same log as on one stream."""
+    from benchnav_amd import NativeMPPI, synth
+    K, T, B, n, Gs = 1024, 50, 2, 30, 24
+    inst = synth.make_instance(Gs, seed=3)
+    starts = np.array([[0.3, 0.4, 0.5], [Gs * 0.5 - 0.25, Gs * 0.5 - 0.35, 0.6]], np.float32)     # lower-left and upper-right corner
+    lat = inst.risk.numpy() * 0.5; std = np.full_like(lat, 0.05)
+    logs = {}
+    for overlap in (False, True):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=Gs, resolution=0.5, num_instances=B, shared_map=True, seed=9, overlap=overlap) as pl:
+            pl.set_map(inst.risk.numpy()); pl.set_goal(np.array([Gs * 0.25, Gs * 0.25], np.float32))
+            pl.env_attach(lat, std, goal_threshold=0.5, delta_t=0.1, seed=5)
+            logs[overlap] = pl.episode(n, starts) + (pl.last_actions.copy(),)
+    for a, b_ in zip(logs[False], logs[True]):
+        assert np.array_equal(a, b_)
+    assert logs[True][0][:, 1, :2].max() >= Gs * 0.5 - 0.4          # the second rover stays near the upper limits for a while
+
+
 def test_big_batches_behind_pending_work_do_not_crowd_each_other_out():
     """A waiting workgroup holds its slot, and two launches that become eligible at the same instant are not dispatched
     fairly: the successor's waiting workgroups can take every slot before its predecessor got one.  Inside a batch that cannot

@@ -345,3 +345,29 @@ def test_ticket_handoff_stress(K, T, B, sampled):
     for b in range(B):
         for a_, b_ in zip(got["one_launch"][b], got["two_launch"][b]):
             assert np.array_equal(a_, b_), b
+
+
+@pytest.mark.parametrize("res,G", [(0.3, 50), (0.1, 200), (0.7, 40), (1.7, 30), (0.45, 64)])
+def test_general_resolution_takes_the_validated_quotient(res, G):
+    """A resolution that is not a power of two: the in-loop cell index divides with the three-instruction correctly rounded
+    quotient, validated on the device over every float the lookups can see when the handle is created (bn_mppi_fast_quotient == 1),
+    and the solve stays bit-exact against the oracle, whose lookup is the reference's true division (grid_map.py:203)."""
+    from benchnav_amd import NativeMPPI, synth
+    from oracle import oracle as O
+    K, T = 512, 40
+    rng = np.random.default_rng(int(res * 100))
+    R = synth.iid_risk_map(G, 3).numpy()
+    ext = G * res
+    state = np.array([0.31 * ext, 0.43 * ext, -0.4], np.float32)
+    goal = np.array([0.7 * ext, 0.6 * ext], np.float32)
+    eps = rng.standard_normal((K, T, 2)).astype(np.float32)
+    mean = np.clip(rng.standard_normal((T, 2)) * 0.2 + [0.7, 0.0], [0, -1], [1, 1]).astype(np.float32)
+    orc = O.solve(O.make_params(K, T, G, res, goal, trig=O.TRIG_SPEC), R, state, mean, eps)
+    for kernel in ("auto", "role", "wave"):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=res, store_controls=True, kernel=kernel) as pl:
+            assert pl.fast_quotient() == 1
+            pl.set_map(R); pl.set_goal(goal); pl.set_mean(mean)
+            us, xs = pl.solve(state, eps)
+            assert_oracle_parity(oracle_metrics(native_outputs(pl, us, xs), orc), ctx=f"res={res} {kernel}")
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5) as pl:
+        assert pl.fast_quotient() == 2

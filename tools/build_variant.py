@@ -6,5 +6,5 @@ from benchnav_amd import build as b
 name, flags = sys.argv[1], sys.argv[2:]
 out = os.path.join(ROOT, "tools", "_ablate", f"lib_{name}.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call([b.hipcc(), *b.HIPCC_FLAGS, *flags, "-x", "hip", *[os.path.join(b.CSRC, s) for s in b.SOURCES], "-o", out])
+subprocess.check_call([b.hipcc(), *b.HIPCC_FLAGS, "-DBN_EXPERIMENTS", *flags, "-x", "hip", *[os.path.join(b.CSRC, s) for s in b.SOURCES], "-o", out])
 print("built", out)

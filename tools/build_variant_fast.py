@@ -12,7 +12,7 @@ args = [a for a in args if a != "--timing"]
 name, flags = args[0], args[1:]
 out_dir = os.path.join(ROOT, "tools", "_ablate")
 os.makedirs(out_dir, exist_ok=True)
-compile_flags = [f for f in b.HIPCC_FLAGS if f != "-shared"]
+compile_flags = [f for f in b.HIPCC_FLAGS if f != "-shared"] + ["-DBN_EXPERIMENTS"]
 base_dir = os.path.join(b.LIB_DIR, "obj")
 if timing:
     flags = ["-DBN_TIMING"] + flags
@@ -27,7 +27,10 @@ if timing:
         assert pr.wait() == 0
 obj = os.path.join(out_dir, f"role_philox_{name}.o")
 subprocess.check_call([b.hipcc(), *compile_flags, *flags, "-x", "hip", "-c", os.path.join(b.CSRC, "rollout_role_philox.hip"), "-o", obj])
-others = [os.path.join(base_dir, os.path.splitext(s)[0] + ".o") for s in b.SOURCES if s != "rollout_role_philox.hip"]
+# the host side as well: its experiment switches (environment variables) exist only with -DBN_EXPERIMENTS
+capi = os.path.join(out_dir, f"capi_{name}.o")
+subprocess.check_call([b.hipcc(), *compile_flags, *flags, "-x", "hip", "-c", os.path.join(b.CSRC, "mppi_capi.cpp"), "-o", capi])
+others = [capi] + [os.path.join(base_dir, os.path.splitext(s)[0] + ".o") for s in b.SOURCES if s not in ("rollout_role_philox.hip", "mppi_capi.cpp")]
 out = os.path.join(out_dir, f"lib_{name}.so")
 subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o", out])
 print("built", out)

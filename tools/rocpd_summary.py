@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Export judge-readable CSV summaries from rocprofv3's rocpd SQLite output.
 
-    python tools/rocpd_summary.py stats  <results.db> <out.csv>     # per kernel x grid: calls, avg/min/max us
+    python tools/rocpd_summary.py stats  <results.db> <out.csv>     # per kernel x grid: calls, avg/min/max us, completion cadence
     python tools/rocpd_summary.py pmc    <results.db> <out.csv>     # per kernel x grid x counter: avg/min/max value
 """
 import csv
@@ -17,7 +17,26 @@ def main():
         rows = c.execute("""select name, grid_x, grid_y, workgroup_x, count(*), avg(duration)/1e3, min(duration)/1e3,
                                    max(duration)/1e3, sum(duration)/1e3, max(vgpr_count), max(sgpr_count), max(lds_size)
                             from kernels group by name, grid_x, grid_y, workgroup_x order by sum(duration) desc""").fetchall()
-        hdr = ["kernel", "grid_x", "grid_y", "workgroup_x", "calls", "avg_us", "min_us", "max_us", "total_us", "vgpr", "sgpr", "lds_bytes"]
+        hdr = ["kernel", "grid_x", "grid_y", "workgroup_x", "calls", "avg_us", "min_us", "max_us", "total_us", "vgpr", "sgpr", "lds_bytes",
+               "cadence_med_us", "cadence_p10_us", "back_to_back"]
+        # Completion cadence: the median difference of consecutive dispatch END timestamps of a kernel x grid.  With overlapped launches
+        # two dispatches are in flight and each one's duration includes its wait for the predecessor's partials, so avg_us is about
+        # twice the rate at which solves complete; the cadence is that rate, from the same trace.  Only differences inside a
+        # back-to-back run count (below 5x the kernel's minimum duration: the gaps between bench legs and repeats are left out).
+        cols = {r[1] for r in c.execute("pragma table_info(kernels)").fetchall()}
+        end_col = "end" if "end" in cols else ("end_timestamp" if "end_timestamp" in cols else None)
+        cad = {}
+        if end_col:
+            ends = {}
+            for name, gx, gy, wx, e in c.execute(f'select name, grid_x, grid_y, workgroup_x, "{end_col}" from kernels order by "{end_col}"'):
+                ends.setdefault((name, gx, gy, wx), []).append(e)
+            for (key, es), r in ((kv, None) for kv in ends.items()):
+                d = [b - a for a, b in zip(es, es[1:])]
+                lim = 5e3 * next(x[6] for x in rows if (x[0], x[1], x[2], x[3]) == key)      # 5 x min duration, in ns
+                d = sorted(x for x in d if 0 < x < lim)
+                if d:
+                    cad[key] = (d[len(d) // 2] / 1e3, d[len(d) // 10] / 1e3, len(d))
+        rows = [tuple(r) + cad.get((r[0], r[1], r[2], r[3]), ("", "", 0)) for r in rows]
     else:
         rows = c.execute("""select kernel_name, grid_size_x, grid_size_y, counter_name, count(*), avg(value), min(value), max(value)
                             from counters_collection group by kernel_name, grid_size_x, grid_size_y, counter_name
