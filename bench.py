@@ -424,10 +424,12 @@ def main():
         s_o, ms_o = leg(plo, state_dev, eps_ring, max(300, a.steps))
         assert plo.arithmetic() == "reference_order"
         plo.close()
-        out["reference_order"] = {"value": 1.0 / s_o, "unit": "solves/s", "us_per_solve": s_o * 1e6, "launches_per_solve": 2,
+        out["reference_order"] = {"value": 1.0 / s_o, "unit": "solves/s", "us_per_solve": s_o * 1e6, "launches_per_solve": 1,
                                   "slowdown_vs_default": s_o / (med / a.steps) if not sustained else s_o / (sustained["ms_per_step"] * 1e-3),
                                   "note": "same workload with BN_FLAG_REFERENCE_ORDER: sincos of every step's heading and x + ((trav v) cos) dt as "
-                                          "robot_model.py:86-88 writes it (one-wave kernel + stand-alone tail); see parity_census for what it buys"}
+                                          "robot_model.py:86-88 writes it, on the same kernels (rollout_role_ref_*.hip: the chain wave integrates the "
+                                          "heading itself); see parity_census for what it buys.  Batched launches and the ticket paths pay 1-8 % for it "
+                                          "(tools/ref_rate.py), this single-instance latency path ~45 %"}
         # ---- batched: 64 instances per launch on this GPU (HBM-relevant regime) -------------------
         if not a.no_batched:
             B = a.batched_instances
@@ -455,6 +457,16 @@ def main():
                     res_b["no_overlap"] = r_
                 else:
                     res_b[lean] = r_
+            # the same 64-instance launch in the reference's operation order
+            plq = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=RES, num_instances=B, device_id=dev,
+                             stream=stream.cuda_stream, overlap=not a.no_overlap, reference_order=True)
+            for b, it in enumerate(insts):
+                plq.set_map(it.risk.numpy(), b)
+                plq.set_goal(it.goal.numpy(), b)
+            s_q, ms_q = leg(plq, states, ring, nb)
+            plq.close()
+            out["reference_order"]["batched"] = {"instances_per_launch": B, "value": B / s_q, "unit": "solves/s", "ms_per_launch": s_q * 1e3,
+                                                 "slowdown_vs_default": s_q / (B / res_b[False]["value"])}
             # a launch large enough for the one-wave throughput kernel (auto-selected above ~1900 workgroups)
             BL = 256
             large = {}
@@ -537,9 +549,14 @@ def main():
         # same line (configs[3]: 64 instances sharded 64/N per GPU; configs[4]: one K=16384 solve sharded by rollouts), each with
         # its own roofline and per-rank times -- what `--workload c4|c5` prints as a line of its own.  Every rank takes part.
         for which in ("c4", "c5"):
-            o = run_workload(a, which, min(a.steps, 50), rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev)
-            if rank == 0:
-                out["sharded_" + which] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "repeats", "scaling", "per_rank_seconds", "config", "roofline")}
+            try:
+                o = run_workload(a, which, min(a.steps, 50), rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev)
+                if rank == 0:
+                    out["sharded_" + which] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "repeats", "scaling", "per_rank_seconds", "config", "roofline")}
+            except Exception as e:                           # the headline above stands whatever happens to a rider
+                print(f"rank {rank}: sharded_{which} failed: {e!r}", file=sys.stderr)
+                if rank == 0:
+                    out["sharded_" + which] = {"error": repr(e)[:500]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds, host_threads)
     if rank == 0:

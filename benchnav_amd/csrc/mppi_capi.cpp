@@ -506,10 +506,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     // global memory (the reference's index clamp, grid_map.py:209), like BN_FLAG_NO_LDS_WINDOW.
     const bool wide_limits = span_x > (float)cfg->grid_size * (1.0f + 1e-6f) || span_y > (float)cfg->grid_size * (1.0f + 1e-6f);
     if ((cfg->flags & BN_FLAG_NO_LDS_WINDOW) || wide_limits) p.WN = 0;
-    // Slow path: the reference-order arithmetic, or a horizon whose control tile does not fit the role kernels' LDS
-    // (MPPI.__init__ takes any horizon, mppi.py:25).  The one-wave kernel keeps its controls in HBM and has no tile: rollouts +
-    // stand-alone tail, two launches per solve, one stream.
-    h->slow_path = p.ref_order != 0;
+    // Slow path: a horizon whose control tile does not fit the role kernels' LDS (MPPI.__init__ takes any horizon, mppi.py:25), or
+    // the reference-order arithmetic in sampled-slip mode (its fused kernel has no such variant).  The one-wave kernel keeps its
+    // controls in HBM and has no tile: rollouts + stand-alone tail, two launches per solve, one stream.  (The reference order by
+    // itself runs on every kernel: rollout_role_ref_*.hip, rollout_wave_ref.hip.)
+    h->slow_path = p.ref_order != 0 && (cfg->flags & BN_FLAG_SAMPLED_SLIP) != 0;
     if (!h->slow_path) {
         if (bn::rollout_lds_bytes(p) > lds_budget) p.WN = 0;
         if (bn::rollout_lds_bytes(p) > lds_budget) { h->slow_path = true; p.WN = wide_limits || (cfg->flags & BN_FLAG_NO_LDS_WINDOW) ? 0 : std::min(p.G + 1, 2 * p.reach + 1); }
@@ -685,6 +686,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     if (rc == BN_OK && may_overlap) {
         int *probe = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 1) * bn::kFlagStride);      // the spare counter slot
         for (int q = 0; rc == BN_OK && q + 1 < h->n_streams; ++q) {
+            bool found = false;
             for (int attempt = 0; attempt < 8; ++attempt) {
                 int seen = 0;
                 if (hipMemset(probe, 0, 2 * sizeof(int)) != hipSuccess || bn::launch_queue_probe(probe, h->stream, h->xstream[q], h->n_cus) != hipSuccess ||
@@ -694,12 +696,17 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
                     rc = fail(BN_ERR_HIP, "probing the streams of overlapped launches failed");
                     break;
                 }
-                if (seen) break;
+                if (seen) { found = true; break; }
+                if (attempt == 7) break;                   // (the stream in hand has been probed and failed: do not swap it for an unprobed one)
                 hipStream_t fresh = nullptr;
                 if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
                 h->parked.push_back(h->xstream[q]);        // kept alive until destroy: destroying it would hand its queue slot to the next one
                 h->xstream[q] = fresh;
             }
+            if (std::getenv("BN_DEBUG_CREATE")) std::fprintf(stderr, "[bn_mppi_create] extra stream %d: %s after %zu replacement(s)\n", q, found ? "dispatches concurrently" : "NO concurrent queue found", h->parked.size());
+            // No stream that dispatches concurrently with the handle's: launches of a batch would not overlap, and workgroups waiting
+            // on the device for a predecessor the queue has not started yet would only burn their bounded waits.  One stream then.
+            if (!found && rc == BN_OK) h->overlap_off = true;
         }
         (void)hipMemset(probe, 0, 2 * sizeof(int));
     }
@@ -1199,6 +1206,12 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     static const bool exp_self_tail = exp_env("BN_SELF_TAIL") != nullptr;
     static const bool exp_align = exp_env("BN_NO_ALIGN") == nullptr;
     if (!exp_align) idle = false;                                   // (only the stream assignment below looks at it from here on)
+    // Launches big enough to crowd each other out start on the handle's OWN stream, whatever that costs at the batch's end.  Aligning
+    // the round robin to end there puts solve 0 of an even batch on the internal stream -- a queue that has been idle since the last
+    // batch and wakes up later than the handle's, which has just carried the caller's work: solve 1 was then dispatched BEFORE solve 0,
+    // its waiting workgroups took the slots solve 0 needed, and the bounded waits expired (round 4, tools/_seq tests: 3-7 of 18 fresh
+    // 64-instance handles with even batch lengths, none with odd ones; it is what made test_big_batches_... fail one run in eight).
+    if (2 * (size_t)h->p.B * (h->p.nblk + 1) > slots) idle = false;
     int rc = BN_OK;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;

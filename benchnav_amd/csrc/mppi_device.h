@@ -269,7 +269,7 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
         c.th = wrap_angle(tn);                                         // :90
         c.x = clampf(xn, p.x0, p.x_hi);                                // :93
         c.y = clampf(yn, p.y0, p.y_hi);                                // :94
-        c.trav = LDSWIN ? trav_window<GEO, 0>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
+        c.trav = LDSWIN ? trav_window<GEO, ASMIDX>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
         return;
     }
     if (!PREP) chain_prepare(p, c, u0, u1);
@@ -1191,6 +1191,9 @@ static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n 
 hipError_t launch_rollout_role_philox(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_kt2(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_t2k(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_role_ref_philox(const SolveParams &p, hipStream_t s);   // rollout_role_ref_*.hip: BN_FLAG_REFERENCE_ORDER
+hipError_t launch_rollout_role_ref_kt2(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_role_ref_t2k(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_wave(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_rollout_wave_ref(const SolveParams &p, EpsMode mode, hipStream_t s);   // rollout_wave_ref.hip
 

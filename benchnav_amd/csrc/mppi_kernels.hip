@@ -428,6 +428,12 @@ size_t finish_lds_bytes_for(SolveParams p, bool sampled)
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)
 {
     if (p.wave_kernel) return launch_rollout_wave(p, mode, s);
+    if (p.ref_order)
+        switch (mode) {
+        case kEpsPhilox: return launch_rollout_role_ref_philox(p, s);
+        case kEpsKT2: return launch_rollout_role_ref_kt2(p, s);
+        default: return launch_rollout_role_ref_t2k(p, s);
+        }
     switch (mode) {
     case kEpsPhilox: return launch_rollout_role_philox(p, s);
     case kEpsKT2: return launch_rollout_role_kt2(p, s);

@@ -21,7 +21,8 @@ def _cell(p, v, origin):
     return int(np.clip(np.floor(np.float32(np.float32(v) - np.float32(origin)) / np.float32(p.res)), 0, p.G - 1))
 
 
-def test_episode_transitions_and_solves_match_the_oracle():
+@pytest.mark.parametrize("arith", ["spec", "reference_order"])
+def test_episode_transitions_and_solves_match_the_oracle(arith):
     import torch
     from oracle import oracle as O
     from benchnav_amd import _capi
@@ -34,10 +35,11 @@ def test_episode_transitions_and_solves_match_the_oracle():
     eps = rng.standard_normal((n, K, T, 2)).astype(np.float32)
     zd, ed = torch.from_numpy(z).cuda(), torch.from_numpy(eps).cuda()
     torch.cuda.synchronize()
-    p = oracle_params_for(fx, O.TRIG_SPEC)
+    p = oracle_params_for(fx, O.TRIG_SPEC if arith == "spec" else O.TRIG_SPEC_PER_STEP)
 
     def run(steps):
-        with native_planner_for(fx) as pl:
+        with native_planner_for(fx, reference_order=(arith == "reference_order")) as pl:
+            assert pl.arithmetic() == arith
             pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
             pl.env_attach(lat_mean, lat_std, goal_threshold=1.0, delta_t=0.1)
             log = pl.episode(steps, fx["state_0"], z_device_ptr=zd.data_ptr(), eps_ptr=ed.data_ptr(),
