@@ -222,3 +222,29 @@ def test_drop_in_class_in_reference_order():
         m = parity_metrics(got, fx, i)
         assert_within(m, TOL_REF, ctx=f"c1_basic solve {i} reference order")
         assert m["cost_outliers"] == 0 and m["X_max"] <= 1e-5
+
+
+@pytest.mark.parametrize("kernel,B,K,T", [("role", 3, 1000, 50), ("wave", 3, 1000, 50), ("lat", 2, 512, 33), ("role", 1, 6000, 20), ("auto", 2, 128, 1)],
+                         ids=["role-B3", "wave-B3", "lat-B2", "ticket-K6000", "T1"])
+def test_reference_order_on_every_kernel_family(kernel, B, K, T):
+    """Every kernel family has its own instantiation in the reference's operation order (rollout_role_ref_*.hip, rollout_wave_ref.hip):
+    forced one at a time, B instances, warm-started second solve included -- bit-exact against the oracle's per-step mode."""
+    import torch
+    from benchnav_amd import NativeMPPI, _capi, synth
+    from oracle import oracle as O
+    G, res = 128, 0.5
+    insts = [synth.make_instance(G, seed=50 + b, jitter=True) for b in range(B)]
+    rng = np.random.default_rng(K + T)
+    eps = rng.standard_normal((2, B, K, T, 2)).astype(np.float32)
+    states = np.stack([it.start.numpy() for it in insts]).astype(np.float32)
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=res, num_instances=B, store_controls=True, kernel=kernel,
+                    reference_order=True) as pl:
+        assert pl.arithmetic() == "reference_order" and pl.launches_per_solve() == 1
+        for b, it in enumerate(insts):
+            pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
+        us0, _ = pl.solve(states, eps[0])
+        us1, xs1 = pl.solve(states, eps[1])                             # warm-started from the kernel's own U*
+        for b, it in enumerate(insts):
+            p = O.make_params(K, T, G, res, it.goal.numpy(), trig=O.TRIG_SPEC_PER_STEP)
+            orc = O.solve(p, it.risk.numpy(), states[b], us0[b], eps[1, b])
+            assert_oracle_parity(oracle_metrics(native_outputs(pl, us1, xs1, b), orc), ctx=f"{kernel} instance {b}")
