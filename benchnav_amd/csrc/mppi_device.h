@@ -466,7 +466,23 @@ __device__ __forceinline__ void st(float *ptr, float v) { if (AGENT) store_agent
 __device__ __forceinline__ unsigned long long *flag_ctr(unsigned long long *base, int i) { return base + (size_t)i * kFlagStride; }
 
 // The error word lives in pinned host memory (SolveParams::err): a system-scope store, so that the host sees it without a copy.
-__device__ __forceinline__ void raise_wait_expired(int *err) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// ... and in a device word (SolveParams::err_dev) that every later WRITER of the warm-start mean looks at first: a launch whose wait
+// expired goes on with incomplete partials, and whatever is merged from them must not reach `mean` -- it is the one piece of state
+// the re-run starts from (mean_snap is taken from it by the first launch of a stretch, which in exactly this situation may run
+// LATE: round 4 saw NaN survive a repair that way).  The flag is raised before the workgroup publishes anything, so whoever sees
+// its counts sees the flag.
+__device__ __forceinline__ void raise_wait_expired(const SolveParams &p)
+{
+    __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool batch_spoiled(const SolveParams &p)
+{
+#ifdef BN_NO_SPOIL_GUARD                              // experiments (tools/recovery_stress.py): the behaviour before the guard
+    return false;
+#endif
+    return p.err_dev != nullptr && __hip_atomic_load(p.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 // First launch of the batches enqueued since the host last checked the error word: workgroup 0 of every instance keeps the mean
 // this solve samples around (ml, in LDS), so that the host can re-run those batches on one stream should a wait expire.
@@ -476,13 +492,13 @@ __device__ __forceinline__ void snapshot_mean(const SolveParams &p, int b, const
 }
 
 template <int SLEEP = 1>
-__device__ __forceinline__ void wait_counter(const unsigned long long *ctr, unsigned long long need, int *err)
+__device__ __forceinline__ void wait_counter(const unsigned long long *ctr, unsigned long long need, const SolveParams &p)
 {
     for (int it = 0; it < (1 << 23) / SLEEP + 1024; ++it) {
         if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
         __builtin_amdgcn_s_sleep(SLEEP);
     }
-    raise_wait_expired(err);
+    raise_wait_expired(p);
 }
 
 // Publish: every wave has seen its own sc1 stores acknowledged (vmcnt 0), the workgroup meets, one lane counts it in.
@@ -825,8 +841,8 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
 {
     if (AGENT) {
         if (threadIdx.x == 0) {
-            wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p.err);   // the solve whose tail this is has published everything
-            wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p.err);               // and the tail before it has left the output buffers
+            wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p);   // the solve whose tail this is has published everything
+            wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);               // and the tail before it has left the output buffers
         }
         __syncthreads();
     }
@@ -869,9 +885,11 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         __syncthreads();
     } else {
         merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
+        const bool spoiled = batch_spoiled(p);                 // a wait of this stretch expired: nothing merged since may reach `mean`
         for (int j = tid; j < 2 * T; j += NT) {
             st<AGENT>(p.ustar + (size_t)b * 2 * T + j, us[j]);
             if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, us[j]);
+            if (spoiled) continue;
             if (p.mean_used) st<AGENT>(p.mean_used + (size_t)b * 2 * T + j, ld<AGENT>(p.mean + (size_t)b * 2 * T + j));   // what this solve sampled around
             st<AGENT>(p.mean + (size_t)b * 2 * T + j, us[j]);  // _previous_action_seq = U*, no shift (mppi.py:217)
         }
@@ -1093,10 +1111,12 @@ __device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, int bl
     // Member of an overlapped batch (p.flag_part): the next launch may be running already -- on the other stream, its workgroups
     // waiting for exactly this -- so what it reads goes out as device-scope stores and the merge counts itself in behind them.
     const bool pubm = p.flag_part != nullptr;
+    const bool spoiled = pubm && batch_spoiled(p);         // (see raise_wait_expired)
     for (int j = tid; j < 2 * T; j += NT) {
         const size_t at = (size_t)b * 2 * T + j;
         if (pubm) {
             store_agent(p.ustar_cur + at, us[j]);
+            if (spoiled) continue;
             if (p.mean_used) store_agent(p.mean_used + at, load_agent(p.mean + at));
             store_agent(p.mean + at, us[j]);
         } else {

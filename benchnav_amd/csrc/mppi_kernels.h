@@ -109,6 +109,7 @@ struct SolveParams {
     unsigned long long wait_part_self;   // self_tail: flag_part[cur_slot][b] value that means "this launch's rollout workgroups have all published"
     unsigned long long wait_tail_self;   // self_tail: flag_tail[b] value that means "every earlier tail (incl. the one this launch carries) is done"
     int *err;                            // pinned host memory: set non-zero (system-scope store) when a bounded wait expired
+    int *err_dev;                        // the same flag in device memory, for the kernels themselves: writers of `mean` skip it once a wait of the stretch has expired
     float *mean_snap;                    // (B, T, 2) or nullptr: workgroup 0 of every instance keeps the mean this solve samples around
                                          // (first launch since the host last checked `err`: where a re-run would start from)
     unsigned long long *gran, *gran_prev;   // (B, nblk, 2+2T) granule copies {value, tag} of this / the previous solve's partial rows

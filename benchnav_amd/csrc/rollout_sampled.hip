@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
             }
         }
         if (ovs) {
-            if (tid == 0) wait_counter<16>(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p.err);
+            if (tid == 0) wait_counter<16>(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p);
             __syncthreads();
             for (int j = tid; j < 2 * T; j += kSampledThreads) {
                 const float m = load_agent(p.mean + (size_t)b * 2 * T + j);
