@@ -1008,22 +1008,49 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         c.trav = trav_lookup<GEO, LDSWIN, true>(p, win, map, w, c.x, c.y);
         float *Xs = xl;                              // staged in LDS, written out coalesced below
         float xn, yn, tn;
-        chain_step<GEO, LDSWIN, true, true, false, 0, REF>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
-        Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
-        int t = 1;
-        for (; t + 4 <= T; t += 4) {                       // controls of four steps read up front (LDS latency off the chain)
-            float uq[4][2];
+        if constexpr (REF) {
+            chain_step<GEO, LDSWIN, true, true, false, 0, true>(p, win, map, w, c, us[0], us[1], xn, yn, tn);
+            Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
+            int t = 1;
+            for (; t + 4 <= T; t += 4) {                   // controls of four steps read up front (LDS latency off the chain)
+                float uq[4][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; }
+                for (int i = 0; i < 4; ++i) { uq[i][0] = us[2 * (t + i)]; uq[i][1] = us[2 * (t + i) + 1]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                chain_step<GEO, LDSWIN, false, true, false, 0, REF>(p, win, map, w, c, uq[i][0], uq[i][1], xn, yn, tn);
-                Xs[3 * (t + i) + 0] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
+                for (int i = 0; i < 4; ++i) {
+                    chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, uq[i][0], uq[i][1], xn, yn, tn);
+                    Xs[3 * (t + i) + 0] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
+                }
             }
-        }
-        for (; t < T; ++t) {
-            chain_step<GEO, LDSWIN, false, true, false, 0, REF>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn);
-            Xs[3 * t + 0] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+            for (; t < T; ++t) {
+                chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn);
+                Xs[3 * t + 0] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+            }
+        } else {
+            // The chain form of the latency kernel (round 4): the next step's controls are folded into its factors at the end of each
+            // step, under the gather's latency (PREP), and the window index is the three-instruction form (ASMIDX with the LDS window).
+            // Same operations per step, so the same bits; this serial rollout is the last thing between a batch's final solve and
+            // its results (4.5 -> ~3.8 us at T = 50), and part of every synchronous forward().
+            constexpr int AI = LDSWIN ? 1 : 0;
+            chain_prepare(p, c, us[0], us[1]);
+            chain_step<GEO, LDSWIN, true, true, true, AI>(p, win, map, w, c, us[0], us[1], xn, yn, tn, T > 1 ? us[2] : 0.0f, T > 1 ? us[3] : 0.0f);
+            Xs[0] = xn; Xs[1] = yn; Xs[2] = tn;
+            int t = 1;
+            for (; t + 4 <= T; t += 4) {                   // controls of four steps (and the first of the next four) read up front
+                float uq[5][2];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { const int tt = min(t + i, T - 1); uq[i][0] = us[2 * tt]; uq[i][1] = us[2 * tt + 1]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    chain_step<GEO, LDSWIN, false, true, true, AI>(p, win, map, w, c, uq[i][0], uq[i][1], xn, yn, tn, uq[i + 1][0], uq[i + 1][1]);
+                    Xs[3 * (t + i) + 0] = xn; Xs[3 * (t + i) + 1] = yn; Xs[3 * (t + i) + 2] = tn;
+                }
+            }
+            for (; t < T; ++t) {
+                const int tt = min(t + 1, T - 1);
+                chain_step<GEO, LDSWIN, false, true, true, AI>(p, win, map, w, c, us[2 * t], us[2 * t + 1], xn, yn, tn, us[2 * tt], us[2 * tt + 1]);
+                Xs[3 * t + 0] = xn; Xs[3 * t + 1] = yn; Xs[3 * t + 2] = tn;
+            }
         }
         Xs[3 * T + 0] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
         BN_STAMP(11);
