@@ -52,6 +52,18 @@ def _case(seed):
 
 @pytest.mark.parametrize("seed", range(128))
 def test_random_configuration_matches_oracle(seed):
+    _random_configuration(seed, False)
+
+
+@pytest.mark.parametrize("seed", range(400, 464))
+def test_random_configuration_matches_oracle_in_reference_order(seed):
+    """The same knobs with BN_FLAG_REFERENCE_ORDER (round 4): the reference-order instantiations of every kernel the knobs select --
+    latency / role / ticket, with and without the LDS window, one- and two-launch -- against the oracle's per-step mode; action
+    bounds up to |omega| = 2 at dt = 0.1 stay below the 0.5 rad per step where the default arithmetic ends, so the flag decides."""
+    _random_configuration(seed, True)
+
+
+def _random_configuration(seed, ref):
     import torch
     from oracle import oracle as O
     from benchnav_amd import NativeMPPI, _capi
@@ -59,12 +71,13 @@ def test_random_configuration_matches_oracle(seed):
     K, T, G = c["K"], c["T"], c["G"]
     inv_var = (np.float32(1) / (np.asarray(c["sigma"], np.float32) ** 2)).tolist()
     p = O.make_params(K, T, G, c["res"], c["goal"], thr=c["thr"], lambda_=c["lam"], sigma=c["sigma"], inv_var=inv_var,
-                      u_min=c["u_min"], u_max=c["u_max"], x_limits=c["xl"], y_limits=c["yl"], trig=O.TRIG_SPEC)
+                      u_min=c["u_min"], u_max=c["u_max"], x_limits=c["xl"], y_limits=c["yl"], trig=O.TRIG_SPEC_PER_STEP if ref else O.TRIG_SPEC)
     orc = O.solve(p, c["R"], c["state"], c["mean"], c["eps"])
     ctx = {k: v for k, v in c.items() if k not in ("R", "eps", "mean")}
     with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=c["res"], x_limits=list(c["xl"]), y_limits=list(c["yl"]),
                     sigmas=c["sigma"], inv_var=inv_var, lambda_=c["lam"], u_min=c["u_min"], u_max=c["u_max"], stuck_threshold=c["thr"],
-                    store_controls=True, lds_window=c["window"], pipeline=c["pipeline"], stream=0) as pl:
+                    store_controls=True, lds_window=c["window"], pipeline=c["pipeline"], stream=0, reference_order=ref) as pl:
+        assert pl.arithmetic() == ("reference_order" if ref else "spec")
         pl.set_map(c["R"]); pl.set_goal(c["goal"]); pl.set_mean(c["mean"])
         st = torch.from_numpy(c["state"]).cuda()
         if c["t2k"]:
