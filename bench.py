@@ -548,6 +548,20 @@ def main():
         # A multi-GPU run of the DEFAULT command: the two BASELINE configurations that name 8 GPUs ride along as objects of the
         # same line (configs[3]: 64 instances sharded 64/N per GPU; configs[4]: one K=16384 solve sharded by rollouts), each with
         # its own roofline and per-rank times -- what `--workload c4|c5` prints as a line of its own.  Every rank takes part.
+        # ... under a watchdog: these riders are the only part of a multi-GPU run that has never executed on more than one GPU.  Should
+        # a collective inside them hang, every rank gives up after 120 s and rank 0 prints the line it has (the headline above) --
+        # a rider must not be able to take the measurement down with it.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out.setdefault("sharded_c4", {"error": "timed out"}); out.setdefault("sharded_c5", {"error": "timed out"})
+                out["parity_census"] = parity_census()
+                emit(out)
+            os._exit(0)
+        dog = threading.Timer(120.0, give_up)
+        dog.daemon = True
+        dog.start()
         for which in ("c4", "c5"):
             try:
                 o = run_workload(a, which, min(a.steps, 50), rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev)
@@ -557,6 +571,7 @@ def main():
                 print(f"rank {rank}: sharded_{which} failed: {e!r}", file=sys.stderr)
                 if rank == 0:
                     out["sharded_" + which] = {"error": repr(e)[:500]}
+        dog.cancel()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(inst, a.cpu_seconds, host_threads)
     if rank == 0:
