@@ -7,17 +7,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _unsharded(K, T, G, inst, mean, seed, eps=None):
+def _unsharded(K, T, G, inst, mean, seed, eps=None, **kw):
     import torch
     from benchnav_amd import NativeMPPI
-    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, store_controls=True, seed=seed, pipeline=False) as pl:
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, store_controls=True, seed=seed, pipeline=False, **kw) as pl:
         pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy()); pl.set_mean(mean)
         us, xs = pl.solve(inst.start.numpy(), eps)
         return dict(Ustar=us[0], Xstar=xs[0], w=pl.weights(), cost=pl.costs(), X=pl.states(), U=pl.controls())
 
 
-@pytest.mark.parametrize("K,T,world", [(4096, 50, 2), (4096, 50, 4), (16384, 100, 8), (1024, 33, 3)], ids=["w2", "w4", "c5-w8", "ragged-w3"])
-def test_sharded_solve_is_bit_identical_to_the_unsharded_one(K, T, world):
+@pytest.mark.parametrize("K,T,world,ref_order", [(4096, 50, 2, False), (4096, 50, 4, False), (16384, 100, 8, False), (1024, 33, 3, False), (4096, 50, 4, True)],
+                         ids=["w2", "w4", "c5-w8", "ragged-w3", "w4-reference-order"])
+def test_sharded_solve_is_bit_identical_to_the_unsharded_one(K, T, world, ref_order):
     import torch
     from benchnav_amd import NativeMPPI, _capi, synth
     from benchnav_amd.sharding import shard_rollouts
@@ -25,12 +26,12 @@ def test_sharded_solve_is_bit_identical_to_the_unsharded_one(K, T, world):
     inst = synth.make_instance(G, seed=4)
     rng = np.random.default_rng(4)
     mean = np.clip(rng.standard_normal((T, 2)) * 0.2 + [0.6, 0.0], [0, -1], [1, 1]).astype(np.float32)
-    ref = _unsharded(K, T, G, inst, mean, seed=123)
+    ref = _unsharded(K, T, G, inst, mean, seed=123, reference_order=ref_order)
     st = inst.start.cuda()
     planners, parts = [], []
     for r in range(world):
         first, count = shard_rollouts(K, world, r)
-        pl = NativeMPPI(horizon=T, num_samples=count, grid_size=G, resolution=0.5, store_controls=True, seed=123, stream=0)
+        pl = NativeMPPI(horizon=T, num_samples=count, grid_size=G, resolution=0.5, store_controls=True, seed=123, stream=0, reference_order=ref_order)
         pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy()); pl.set_mean(mean); pl.set_rollout_offset(first)
         pl.shard_rollout_async_device(st.data_ptr())
         ptr, n, ps = pl.shard_partials()
