@@ -177,6 +177,10 @@ struct bn_mppi {
     int *h_err = nullptr, *d_err = nullptr;     // host address / device address of the same word
     unsigned long long *h_mail = nullptr, *d_mail = nullptr;   // (B, 2) granules {U*[0][d], solve index + 1}: see bn_mppi_first_action
     float *d_mean_snap = nullptr;
+    float *d_state_snaps = nullptr;             // [snap_cap][B][3]: the states every journalled batch started from, kept by its first launch
+    size_t snap_cap = 0;                        // (SolveParams::state_snap): a re-run reads these, not the caller's buffer
+    size_t snap_slot = 0;                       // slot of the batch being enqueued
+    bool arm_state_snap = false;                // the next launch fills it
     struct BatchRec { int32_t n; const float *states; const float *eps; bn_noise_kind noise; int32_t eps_ring; int64_t eps_stride; bool episode; const float *z; };
     std::vector<BatchRec> journal;
     bool journal_lost = false;                  // something not replayable happened since the last clean check (or too many batches)
@@ -293,18 +297,29 @@ int check_instance(const bn_mppi *h, int32_t instance, bool allow_all)
 
 constexpr size_t kJournalCap = 4096;
 
-void journal_push(bn_mppi *h, const bn_mppi::BatchRec &r, bool replayable)
+// Called before the first launch of a batch that journal_push may record: that launch copies the states it reads into the slot
+// the record will point at.  (Costs nothing on the host; one predicated 12-byte store in the kernel.)
+void journal_arm_states(bn_mppi *h)
+{
+    if (h->replaying) return;
+    h->snap_slot = h->journal.size();
+    h->arm_state_snap = h->snap_slot < h->snap_cap;
+}
+
+void journal_push(bn_mppi *h, bn_mppi::BatchRec r, bool replayable)
 {
     if (h->replaying) return;
     if (!h->last_batch_overlapped && h->journal.empty()) return;      // nothing in flight that a wait could have spoilt
-    if (!replayable || h->journal.size() >= kJournalCap) { h->journal_lost = true; h->journal.clear(); return; }
+    if (!replayable || h->journal.size() >= std::min(kJournalCap, h->snap_cap) || h->snap_slot != h->journal.size()) { h->journal_lost = true; h->journal.clear(); return; }
+    r.states = h->d_state_snaps + h->snap_slot * (size_t)h->p.B * 3;  // what the batch's first launch kept (journal_arm_states)
     if (!h->journal_lost) h->journal.push_back(r);
 }
 
 // A bounded device-side wait of an overlapped launch expired: that launch computed on incomplete partials, and every solve
 // warm-started from it since is invalid as well.  Bring the handle to rest, forget the counters, and run the journalled batches
-// again on ONE stream from the mean the first of them started from: same inputs (the callers' state / noise buffers, which must
-// stay valid until the synchronisation point that follows a batch, as for any asynchronous call), same Philox positions, hence
+// again on ONE stream from the mean the first of them started from: same inputs (the states each batch's first launch kept in
+// d_state_snaps; the callers' noise buffers, which must stay valid until the synchronisation point that follows a batch, as for
+// any asynchronous call), same Philox positions, hence
 // the results the overlapped launches would have produced.  The handle keeps to one stream from then on: whatever kept a
 // predecessor from becoming resident (another process on the GPU, most likely) may still be there.
 // BN_OK with a warning in bn_last_error() when the re-run succeeded (bn_mppi_recovery_count counts them: consumers enqueued
@@ -322,6 +337,7 @@ int recover_overlap(bn_mppi *h)
     h->overlap_off = true;
     h->overlap_used = false;
     h->arm_snap = false;
+    h->arm_state_snap = false;
     h->in_episode = false;
     *h->h_err = 0;
     std::vector<bn_mppi::BatchRec> recs;
@@ -596,6 +612,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     if (const char *e = exp_env("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
     alloc(&h->d_flags, ((kSlots + 1) * B + 3) * bn::kFlagStride * sizeof(unsigned long long));      // [kSlots][B] + [B] counters, a spare slot, the device error word
     alloc(&h->d_mean_snap, B * T * 2 * 4);
+    h->snap_cap = std::max<size_t>(64, std::min<size_t>(4096, ((size_t)16 << 20) / ((size_t)B * 12)));      // at most 16 MB of them (B <= 341: the journal's own 4096)
+    alloc(&h->d_state_snaps, h->snap_cap * B * 3 * 4);
     if (rc == BN_OK) {
         if (hipHostMalloc((void **)&h->h_err, 64, hipHostMallocMapped) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostMalloc (error word) failed");
         else if (hipHostGetDevicePointer((void **)&h->d_err, h->h_err, 0) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostGetDevicePointer failed");
@@ -757,6 +775,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
     if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->d_mean_snap) (void)hipFree(h->d_mean_snap);
+    if (h->d_state_snaps) (void)hipFree(h->d_state_snaps);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -928,6 +947,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     h->last_mode = mode;
     const int cur3 = (int)(h->solves % kSlots), prev3 = (int)((h->solves + kSlots - 1) % kSlots);    // per-solve buffers: kSlots slots
     p.solve = h->solves;
+    if (h->arm_state_snap) { p.state_snap = h->d_state_snaps + h->snap_slot * (size_t)p.B * 3; h->arm_state_snap = false; }
     p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state_copy = h->d_state_copy[cur3];
     p.part_prev = h->d_part[prev3]; p.cost_prev = h->d_cost[prev3]; p.state_prev = h->d_state_copy[prev3];
     if (h->pipelined && !shard_rollout) {
@@ -1061,6 +1081,7 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     if (h && !h->replaying && !h->journal.empty()) {
         // a single solve behind overlapped batches whose error word has not been checked yet: journalled as a batch of one
         h->last_batch_overlapped = false;
+        journal_arm_states(h);
         journal_push(h, bn_mppi::BatchRec{1, states, eps, noise, 1, 0, false, nullptr}, states_where == BN_MEM_DEVICE && noise != BN_NOISE_HOST_KT2);
     }
     return solve_impl(h, states, states_where, eps, noise, false);
@@ -1167,6 +1188,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     }
     const bn_mppi::BatchRec rec{n, states, eps, noise, eps_ring, eps_stride, false, nullptr};
     const bool replayable = states_where == BN_MEM_DEVICE && noise != BN_NOISE_HOST_KT2;
+    if (replayable && !h->in_episode) journal_arm_states(h);
     if (!mine) {
         h->last_batch_overlapped = false;
         for (int32_t i = 0; i < n; ++i) {
@@ -1341,6 +1363,7 @@ int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, b
         states0 = h->d_state;
         states_where = BN_MEM_DEVICE;
     }
+    journal_arm_states(h);                            // the first step's launch keeps states0 for a re-run
     h->in_episode = true;
     h->ep_len = 0;
     h->ep_z = z_device;

@@ -110,6 +110,8 @@ struct SolveParams {
     unsigned long long wait_tail_self;   // self_tail: flag_tail[b] value that means "every earlier tail (incl. the one this launch carries) is done"
     int *err;                            // pinned host memory: set non-zero (system-scope store) when a bounded wait expired
     int *err_dev;                        // the same flag in device memory, for the kernels themselves: writers of `mean` skip it once a wait of the stretch has expired
+    float *state_snap;                   // (B, 3) or nullptr: the first launch of a journalled batch keeps the states it was given in memory the handle
+                                         // owns -- a re-run must not depend on the caller's buffer still holding them (round 4)
     float *mean_snap;                    // (B, T, 2) or nullptr: workgroup 0 of every instance keeps the mean this solve samples around
                                          // (first launch since the host last checked `err`: where a re-run would start from)
     unsigned long long *gran, *gran_prev;   // (B, nblk, 2+2T) granule copies {value, tag} of this / the previous solve's partial rows

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kSampledThreads) void rollout_sampled_kernel(const 
         mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
     }
     if (wg.blk == 0 && tid < 3) { if (tpub) store_agent(p.state_copy + b * 3 + tid, p.state[b * 3 + tid]); else p.state_copy[b * 3 + tid] = p.state[b * 3 + tid]; }
+    if (p.state_snap && wg.blk == 0 && tid < 3) p.state_snap[b * 3 + tid] = p.state[b * 3 + tid];   // first launch of a journalled batch
     __syncthreads();
 
     // ---- phase 1: slip draws, then controls, of every step ----
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(64) void rollout_sampled_global_kernel(const SolveP
         mv[j] = m * ((j & 1) ? p.iv1 : p.iv0);
     }
     if (wg.blk == 0 && lane < 3) p.state_copy[b * 3 + lane] = p.state[b * 3 + lane];
+    if (p.state_snap && wg.blk == 0 && lane < 3) p.state_snap[b * 3 + lane] = p.state[b * 3 + lane];
     __syncthreads();
     const size_t Kp = (size_t)p.Kp;
     float *Xb = p.X + (size_t)b * (T + 1) * 3 * Kp + k;

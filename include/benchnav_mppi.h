@@ -196,17 +196,21 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
  *   - the LAST solve of the call and the tail behind it run on the handle's stream, so work enqueued there afterwards is ordered
  *     behind the batch's final results by the queue itself; the internal stream is not joined back -- its kernels have handed
  *     everything over through device counters by then and end within microseconds (bn_mppi_sync waits for both);
- *   - `states` and `eps` are read by every solve of the call: they must stay valid AND UNCHANGED until the synchronisation point
- *     that follows the batch (bn_mppi_sync, a getter, or the caller's own stream synchronisation), as for any asynchronous call.
+ *   - `states` is read by every solve of the call, `eps` block i by solve i: they must stay valid and unchanged until the batch has
+ *     run -- work enqueued on the handle's stream behind the call may overwrite `states` (a host-driven closed loop that keeps
+ *     ONE state buffer: batch, write the next state in stream order, batch);
+ *   - `eps` (caller-provided noise) must stay valid AND UNCHANGED until the synchronisation point that follows the batch
+ *     (bn_mppi_sync, a getter, or the caller's own stream synchronisation): a re-run, see below, reads it again.
  * Device-side waits are bounded (~2 s: another user of the GPU kept a predecessor from becoming resident).  If one expires the
  * launch computes on incomplete partials; the error word it sets lives in pinned host memory and is looked at by EVERY entry
  * point that synchronises (bn_mppi_sync, the getters, the setters, bn_mppi_episode_log ...) and by bn_mppi_flush: the batches
  * enqueued since the last clean synchronisation point are then RE-RUN on one stream from the mean the first of them started
- * from (kept on the device), with the same Philox positions and the callers' state / noise buffers -- the second reason for the
- * "unchanged" rule above: a caller that rewrote its state tensor in place between batches gets the re-run on the NEW contents.
+ * from (kept on the device), with the same Philox positions, the callers' noise buffers, and the states each batch was GIVEN: the
+ * first launch of every journalled batch keeps them in memory the handle owns (ABI 3, round 4; before that a caller that rewrote
+ * its state tensor in place between batches got the re-run on the new contents).
  * The call returns BN_OK with a warning in bn_last_error(), bn_mppi_recovery_count() counts these events (consumers enqueued in
  * stream order BEFORE the synchronisation point have read invalid buffers), and the handle keeps to one stream from then on.
- * BN_ERR_HIP only when the batches cannot be re-run (host-resident inputs, more than 4096 batches without a synchronising call). */
+ * BN_ERR_HIP only when the batches cannot be re-run (host-resident inputs; more than min(4096, 16 MB / (12 B x num_instances), at least 64) batches without a synchronising call). */
 int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
 

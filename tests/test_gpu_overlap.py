@@ -230,6 +230,50 @@ def test_an_expired_wait_is_repaired_by_a_rerun_on_one_stream():
                 assert np.array_equal(a_, c_), (b, j)
 
 
+@pytest.mark.parametrize("K,kw", [(1024, {}), (1024, {"kernel": "role"}), (1024, {"kernel": "wave"}), (8192, {}),
+                                  (1024, {"reference_order": True})],
+                         ids=["lat", "role", "wave", "ticket", "reference-order"])
+def test_a_rerun_does_not_read_the_callers_state_buffer_again(K, kw):
+    """A host-driven closed loop reuses ONE device state buffer: batch, write the next state into it in stream order, batch.  Both
+    batches have read what they needed by the time a later synchronisation point notices an expired wait -- the re-run must start
+    each of them from the states it was GIVEN, not from what the buffer holds by then.  The first launch of every journalled batch
+    keeps its states in handle-owned memory (SolveParams::state_snap); with the test hook: three chained batches from three
+    different states in the same buffer, then the buffer is scribbled over, then the repair -- results equal to a handle that never
+    overlapped.  The same for a single solve behind the batches; on every kernel family, since each keeps the snapshot itself."""
+    import torch
+    from benchnav_amd import _capi, synth
+    T, B = 50, 2
+    insts = [synth.make_instance(G, seed=64 + b) for b in range(B)]
+    st0 = torch.stack([it.start for it in insts])
+    states = [st0, st0 + torch.tensor([0.4, -0.3, 0.2]), st0 + torch.tensor([-0.5, 0.6, -0.4]), st0 + torch.tensor([0.1, 0.2, 0.7])]
+    buf = torch.empty_like(st0).cuda()
+    torch.cuda.synchronize()
+
+    def drive(pl):
+        for i, n in enumerate((4, 5, 3)):
+            torch.cuda.synchronize()                             # the device, not the handle: its journal stays unchecked
+            buf.copy_(states[i]); torch.cuda.synchronize()
+            pl.solve_n_async_device(n, buf.data_ptr())
+        torch.cuda.synchronize()
+        buf.copy_(states[3]); torch.cuda.synchronize()
+        pl.solve_async_device(buf.data_ptr())                    # a single solve behind them
+        torch.cuda.synchronize()
+
+    with _make(K, T, B, insts, False, **kw) as ref:
+        drive(ref)
+        want = _outputs(ref, B, T)
+    with _make(K, T, B, insts, True, **kw) as pl:
+        drive(pl)
+        _capi.check(pl._lib.bn_mppi_debug_expire_wait(pl._h))    # (synchronises the handle's streams first)
+        buf.fill_(float("nan"))                                  # the caller moves on: nothing the batches were given is left
+        torch.cuda.synchronize()
+        got = _outputs(pl, B, T)
+        assert pl.recovery_count() == 1
+    for b in range(B):
+        for j, (a_, c_) in enumerate(zip(got[b], want[b])):
+            assert np.array_equal(a_, c_), (b, j)
+
+
 def test_an_expired_wait_in_an_episode_is_repaired():
     """The device-side closed loop is journalled as a whole: after the hook the log read-back equals the one-stream episode's."""
     from benchnav_amd import _capi, synth
