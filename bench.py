@@ -395,6 +395,14 @@ def main():
             out["sustained"]["note"] = ("the contract's K steps are one short timed region: launch latency of the first solve, the last solve's tail "
                                         "kernel and the synchronisation are paid once per region; this is the same handle over 3000 steps")
             out["fixed_overhead_us_per_timed_region"] = (med / a.steps - sustained["ms_per_step"] * 1e-3) * a.steps * 1e6
+            # what the runtime alone needs for the same bracket around ONE trivial kernel (torch's fill of one element): launch latency
+            # + completion -> host; the part of the fixed cost above that no kernel change can remove (tools/spin_sync.py: the
+            # hipDeviceSchedule* flags do not move it)
+            one = torch.zeros(1, device="cuda")
+            fl = []
+            for _ in range(200):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); one.fill_(1.0); torch.cuda.synchronize(); fl.append(time.perf_counter() - t0)
+            out["runtime_floor_us_one_kernel_region"] = sorted(fl)[len(fl) // 2] * 1e6
 
     if extras:
         def leg(pl_, st_, ring_, n_):

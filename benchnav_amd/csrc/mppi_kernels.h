@@ -39,6 +39,8 @@ struct SolveParams {
                          // one instance on one XCD (workgroup i runs on XCD i % 8), 0 is instance-per-row
     int aux_prio;        // the aux workgroups run at wave priority 3: set when the launch exceeds one resident round, so that they
                          // start late (in slots freed by the first rollout workgroups) and must not finish last
+    int regen_steps;     // one-wave kernel, library noise: the epilogue draws the controls of steps [0, regen_steps) again and reads the rest back
+                         // from the control buffer (multiple of 4; T = everything regenerated, 0 = everything round-tripped): VALU against HBM
     int lean;            // lean mode: the (K,T+1,3) trajectory batch is not materialised (bn_mppi_reroll regenerates rows on demand)
     int ref_order;       // BN_FLAG_REFERENCE_ORDER (or dt * max|omega| > 0.5): every transit evaluates sincos_spec of its own heading and
                          // updates in the reference's operation order, x + ((trav v) cos) dt (robot_model.py:86-88) -- the oracle's trig = 2.
