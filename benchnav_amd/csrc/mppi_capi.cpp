@@ -1230,7 +1230,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // The last launch of a long batch can carry its own tail as a second aux workgroup (SolveParams::self_tail) instead of a tail
     // kernel behind it.  Measured (tools/region_overhead.py, K = 20): 0.7 us better with round 2's kernel, 5 us WORSE since the
     // barrier-free prologue (225.2 vs 230.2 us) -- off unless BN_SELF_TAIL is set; the code stays for the next look at the region's ends.
-    static const bool exp_self_tail = exp_env("BN_SELF_TAIL") != nullptr;
+    const bool exp_self_tail = exp_env("BN_SELF_TAIL") != nullptr;      // (read per batch: tools/region_ab.py toggles it inside one process)
     static const bool exp_align = exp_env("BN_NO_ALIGN") == nullptr;
     if (!exp_align) idle = false;                                   // (only the stream assignment below looks at it from here on)
     // Launches big enough to crowd each other out start on the handle's OWN stream, whatever that costs at the batch's end.  Aligning
