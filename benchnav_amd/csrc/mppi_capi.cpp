@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -334,6 +335,11 @@ int recover_overlap(bn_mppi *h)
     h->tails = 0;
     h->prev_published = false;
     h->tail_pending = false;
+#ifdef BN_EXPERIMENTS
+    fprintf(stderr, "[bn] expired wait: counter %d (B=%d: [slot][b] below %d, tails above) need %d seen %d | solve %d block (%d,%d) have_prev/overlap/cur_slot %d wait_part*1000+wait_tail %d | host: solves %llu tails %llu pub %llu %llu %llu %llu\n",
+            h->h_err[8], h->p.B, kSlots * h->p.B, h->h_err[9], h->h_err[10], h->h_err[11], h->h_err[12], h->h_err[13], h->h_err[14], h->h_err[15],
+            (unsigned long long)h->solves, (unsigned long long)h->tails, (unsigned long long)h->pub[0], (unsigned long long)h->pub[1], (unsigned long long)h->pub[2], (unsigned long long)h->pub[kSlots - 1]);
+#endif
     h->overlap_off = true;
     h->overlap_used = false;
     h->arm_snap = false;
@@ -536,6 +542,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         if (bn::rollout_lds_bytes(p) > lds_budget) p.WN = 0;
         if (bn::rollout_lds_bytes(p) > lds_budget) { h->slow_path = true; p.WN = wide_limits || (cfg->flags & BN_FLAG_NO_LDS_WINDOW) ? 0 : std::min(p.G + 1, 2 * p.reach + 1); }
     }
+    // Sampled slip: the tail's optimal rollout stages a (mean, std) window on top of the plain one -- three windows' worth of LDS.  A
+    // reach that fits the rollout kernels (which fall back to the global gather by themselves, sampled_fused) can still be too much
+    // for the tail; then everything gathers from global memory.  (Round 4: tools/fuzz_sweep.py, seed 2327 -- T = 63, 0.1 m cells,
+    // 1 m/s: a 129 x 129 window, 200 KB in the tail, and the launch failed with "invalid argument".)
+    if ((cfg->flags & BN_FLAG_SAMPLED_SLIP) && !h->slow_path && bn::finish_lds_bytes_for(p, true) > lds_budget) p.WN = 0;
     if (h->slow_path) {
         const bool sampled = (cfg->flags & BN_FLAG_SAMPLED_SLIP) != 0;
         if (bn::wave_lds_bytes(p) > lds_budget || (sampled && bn::finish_lds_bytes_for(p, true) > lds_budget)) p.WN = 0;
@@ -1238,8 +1249,10 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // batch and wakes up later than the handle's, which has just carried the caller's work: solve 1 was then dispatched BEFORE solve 0,
     // its waiting workgroups took the slots solve 0 needed, and the bounded waits expired (round 4, tools/_seq tests: 3-7 of 18 fresh
     // 64-instance handles with even batch lengths, none with odd ones; it is what made test_big_batches_... fail one run in eight).
-    if (2 * (size_t)h->p.B * (h->p.nblk + 1) > slots && !exp_env("BN_ALIGN_BIG")) idle = false;      // (BN_ALIGN_BIG: tools/recovery_stress.py brings the race back)
+    const bool crowd = 2 * (size_t)h->p.B * (h->p.nblk + 1) > slots;
+    if (crowd && !exp_env("BN_ALIGN_BIG")) idle = false;      // (BN_ALIGN_BIG: tools/recovery_stress.py brings the race back)
     int rc = BN_OK;
+    int stamp = 0;
     for (int32_t i = 0; i < n && rc == BN_OK; ++i) {
         const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
         // Stream (and trajectory buffer) of solve i: round robin, except that the LAST solve always runs on the handle's own stream
@@ -1251,7 +1264,46 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         const int q = idle ? (n - 1 - i) % S : (i == n - 1 ? 0 : i % S);
         // A long batch ends with its own tail (see below): on the latency kernel it rides in the last launch as a second aux workgroup.
         const bool own_tail = i == n - 1 && n >= kEagerTailMinBatch && exp_self_tail;
-        rc = solve_impl(h, states, states_where, e, noise, false, true, q ? h->xstream[q - 1] : h->stream, q, own_tail);
+        // Launches big enough to crowd each other out (more than one residency round between two of them): a launch whose workgroups
+        // wait for partials holds slots, and the dispatcher does not share freed slots fairly between two queues -- a successor that
+        // becomes eligible while its predecessor still has workgroups to place can take every slot and starve it until the bounded waits
+        // expire.  In the steady state that cannot happen: launch i+1 becomes eligible when launch i-1 completes, a whole kernel after
+        // launch i did.  The START of a batch is different -- the second launch goes to a queue that has been idle and wakes up late
+        // (8 us and more in the kernel traces): it could be dispatched before the first (the inversion the stream assignment above made
+        // rare), or so late that the THIRD launch, eligible when the first completes, finds it half placed (round 4,
+        // tools/fuzz_features.py: every expiry on a 70-instance planner was the third launch of a batch waiting for workgroups of the
+        // second that never got a slot: one handle in 20 to 400, box by box, each repaired by a re-run).  So the first three launches
+        // are handed over one by one: a one-thread marker kernel in front of a launch stamps pinned host memory when its queue has
+        // reached it, and the host enqueues the next launch only then -- the other queue is woken by a marker of its own right away.
+        // A few microseconds of host time under a first launch of 20 us and more, once per batch.  (The stamps cannot come from the
+        // rollout kernels themselves: two more live scalars in their prologues put the role kernel on the register allocator's
+        // emergency slot, tests/test_build_artifacts.py.)
+        const hipStream_t qs = q ? h->xstream[q - 1] : h->stream;
+        auto seen = [&](int word, hipStream_t wait_out) -> int {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (__atomic_load_n(&h->h_err[word], __ATOMIC_ACQUIRE) != stamp) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {      // something else holds the GPU: wait the launch out
+                    BN_HIP(hipStreamSynchronize(wait_out));
+                    break;
+                }
+            }
+            return BN_OK;
+        };
+        if (crowd && !h->replaying && n >= 3 && i < 3) {
+            if (i == 0) {
+                stamp = (int)(h->solves & 0x3fffffff) + 1;
+                for (int w = 4; w < 8; ++w) __atomic_store_n(&h->h_err[w], 0, __ATOMIC_RELEASE);
+                if (S > 1) BN_HIP(bn::launch_stamp(h->d_err + 5, stamp, h->xstream[0]));      // wakes the other queue
+                BN_HIP(bn::launch_stamp(h->d_err + 4, stamp, qs));
+            } else if (i == 1) {
+                if (int r = seen(4, h->stream)) return r;                                          // the first launch is next in a queue that is being processed
+                if (S > 1) { if (int r = seen(5, h->xstream[0])) return r; }
+                BN_HIP(bn::launch_stamp(h->d_err + 6, stamp, qs));
+            } else {
+                if (int r = seen(6, h->xstream[0])) return r;                                      // ... and so is the second
+            }
+        }
+        rc = solve_impl(h, states, states_where, e, noise, false, true, qs, q, own_tail);
     }
     // A long batch ends with its own tail, enqueued right behind the last solve and BEFORE the join: a tail kernel that comes later
     // (flush, sync, a getter) would sit behind the join's barrier packet, ~10 us of queue processing after the last rollout kernel.

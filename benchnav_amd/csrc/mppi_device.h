@@ -471,8 +471,15 @@ __device__ __forceinline__ unsigned long long *flag_ctr(unsigned long long *base
 // the re-run starts from (mean_snap is taken from it by the first launch of a stretch, which in exactly this situation may run
 // LATE: round 4 saw NaN survive a repair that way).  The flag is raised before the workgroup publishes anything, so whoever sees
 // its counts sees the flag.
-__device__ __forceinline__ void raise_wait_expired(const SolveParams &p)
+__device__ __forceinline__ void raise_wait_expired(const SolveParams &p, const unsigned long long *ctr = nullptr, unsigned long long need = 0)
 {
+#ifdef BN_EXPERIMENTS                                  // which wait it was, for the host's message (tools/_repro*.py)
+    if (ctr && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        p.err[8] = (int)((ctr - p.flag_part) / kFlagStride); p.err[9] = (int)need;
+        p.err[10] = (int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); p.err[11] = (int)p.solve;
+        p.err[12] = blockIdx.x; p.err[13] = blockIdx.y; p.err[14] = p.have_prev * 100 + p.overlap * 10 + p.cur_slot; p.err[15] = (int)p.wait_part * 1000 + (int)p.wait_tail;
+    }
+#endif
     __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (p.err_dev) __hip_atomic_store(p.err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -498,7 +505,7 @@ __device__ __forceinline__ void wait_counter(const unsigned long long *ctr, unsi
         if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
         __builtin_amdgcn_s_sleep(SLEEP);
     }
-    raise_wait_expired(p);
+    raise_wait_expired(p, ctr, need);
 }
 
 // Publish: every wave has seen its own sc1 stores acknowledged (vmcnt 0), the workgroup meets, one lane counts it in.

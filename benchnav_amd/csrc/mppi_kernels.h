@@ -173,6 +173,7 @@ hipError_t launch_env_collision(const SolveParams &p, const float *states, int N
 // set the flag (bounded) and records in [1] whether its first workgroup saw it: only if the two streams dispatch concurrently.
 hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter, int n_cus);
 // every float d in [0, d_max]: does quotient_general's fast form give floor(d / res) (and the same bits for d >= 1e-30)?  *bad = count of failures
+hipError_t launch_stamp(int *word, int value, hipStream_t s);      // one thread: *word = value (system scope) -- a marker in a queue, for the host
 hipError_t launch_quotient_check(float res, float inv_res, float d_max, unsigned long long *bad, hipStream_t s);
 hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipStream_t s);   // 0 sqrt, 1 sin, 2 cos, 3 wrap, 4 wrap_near
 

@@ -564,6 +564,17 @@ hipError_t launch_quotient_check(float res, float inv_res, float d_max, unsigned
     return hipGetLastError();
 }
 
+__global__ void stamp_kernel(int *word, int value)
+{
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_stamp(int *word, int value, hipStream_t s)
+{
+    stamp_kernel<<<1, 1, 0, s>>>(word, value);
+    return hipGetLastError();
+}
+
 hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipStream_t s)
 {
     math_eval_kernel<<<grid_for(n), 256, 0, s>>>(fn, in, out, n);
