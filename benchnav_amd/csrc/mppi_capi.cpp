@@ -7,6 +7,7 @@
 #include "mppi_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdarg>
@@ -83,6 +84,15 @@ bool is_pow2_float(float v)
 // device (its streams still busy); otherwise this batch runs in one stream, which is always safe.
 std::mutex g_overlap_mu;
 std::map<int, bn_mppi *> g_overlap_owner;   // device -> the handle whose overlapped batch was enqueued last
+// ... and nothing ELSE of this process beside it (round 4).  The rule above kept two overlapped batches apart; a differential sweep
+// over pairs of planners (tools/fuzz_features2.py) still saw waits expire: one planner's overlapped batch of latency-kernel
+// launches -- one workgroup per CU, sized for a device it has to itself -- with the other planner's ordinary one-stream launches
+// in between (12 % of the runs of one pattern, depending on the order the handles' queues were created in).  So a batch
+// overlaps only while EVERY other handle on the device is idle (g_handles), and a launch of another handle that arrives while an
+// overlapped batch is in flight is ordered behind that batch's end by events (order_behind_foreign_overlap): no host blocking,
+// the kernels simply do not share the device with waiting workgroups.
+std::map<int, std::vector<bn_mppi *>> g_handles;   // device -> live handles (guarded by g_overlap_mu)
+std::atomic<int> g_overlap_owners{0};              // devices with an owner: the launch path looks at it without the lock
 // ... and one PROCESS per device for launches big enough to crowd each other out: two processes with overlapped 64-instance batches
 // on one GPU both ran into expired waits within a second.  An advisory lock on a per-device file in /tmp, taken (non-blocking) by
 // the first process that overlaps big launches there and held until it exits; a process that does not get it runs those batches
@@ -158,6 +168,7 @@ struct bn_mppi {
     hipStream_t xstream[kMaxStreams - 1] = {};
     std::vector<hipStream_t> parked;            // streams that turned out to share the handle's hardware queue (see bn_mppi_create)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams - 1] = {};
+    hipEvent_t ev_guard[kMaxStreams] = {};      // recorded on this handle's streams BY another handle that must run behind this one's overlapped batch
     unsigned long long *d_flags = nullptr;      // [kSlots][B] flag_part per slot and instance, [B] flag_tail per instance, then int err
     bool role_overlap = false;                  // the role kernel's launches of a batch may overlap too (see bn_mppi_solve_n_async)
     unsigned long long *d_gran[kSlots] = {};   // granule copies of the partial rows per slot (K <= 1024, 2T <= 320)
@@ -664,6 +675,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     }
     if (rc == BN_OK && may_overlap) {
         bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int q = 0; ok && q < h->n_streams; ++q) ok = hipEventCreateWithFlags(&h->ev_guard[q], hipEventDisableTiming) == hipSuccess;
         for (int q = 0; ok && q + 1 < h->n_streams; ++q)
             ok = hipStreamCreateWithFlags(&h->xstream[q], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&h->ev_join[q], hipEventDisableTiming) == hipSuccess;
@@ -748,6 +760,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         bn_mppi_destroy(h);
         return rc;
     }
+    {
+        std::lock_guard<std::mutex> lock(g_overlap_mu);
+        g_handles[h->cfg.device_id].push_back(h);
+    }
     *out = h;
     return BN_OK;
 }
@@ -761,6 +777,9 @@ void bn_mppi_destroy(bn_mppi_t *h)
         std::lock_guard<std::mutex> lock(g_overlap_mu);
         auto it = g_overlap_owner.find(h->cfg.device_id);
         if (it != g_overlap_owner.end() && it->second == h) g_overlap_owner.erase(it);
+        g_overlap_owners.store((int)g_overlap_owner.size(), std::memory_order_relaxed);
+        auto &v = g_handles[h->cfg.device_id];
+        v.erase(std::remove(v.begin(), v.end(), h), v.end());
     }
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost_out,
@@ -786,6 +805,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
     }
     for (hipStream_t ps : h->parked) (void)hipStreamDestroy(ps);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_guard) if (e) (void)hipEventDestroy(e);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
@@ -882,6 +902,29 @@ int bn_mppi_get_mean(bn_mppi_t *h, int32_t instance, float *mean_host)
     return BN_OK;
 }
 
+// A launch of handle h that is not a member of an overlapped batch of its own: if ANOTHER handle's overlapped batch may still be
+// in flight on the device, `st` waits for its end (events recorded on that handle's streams).  See g_handles.
+static int order_behind_foreign_overlap(bn_mppi *h, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_overlap_mu);
+    auto it = g_overlap_owner.find(h->cfg.device_id);
+    if (it == g_overlap_owner.end() || it->second == h || !it->second) return BN_OK;
+    bn_mppi *o = it->second;
+    bool busy = false;
+    for (int q = 0; q < o->n_streams; ++q) {
+        const hipStream_t os = q ? o->xstream[q - 1] : o->stream;
+        if (os == st || (q && !os)) continue;                       // the same stream: ordered anyway
+        if (hipStreamQuery(os) == hipSuccess) continue;
+        busy = true;
+        if (!o->ev_guard[q]) continue;
+        BN_HIP(hipEventRecord(o->ev_guard[q], os));
+        BN_HIP(hipStreamWaitEvent(st, o->ev_guard[q], 0));
+    }
+    (void)hipGetLastError();
+    if (!busy) { g_overlap_owner.erase(it); g_overlap_owners.store((int)g_overlap_owner.size(), std::memory_order_relaxed); }   // its batch is through: nothing to look at until the next one
+    return BN_OK;
+}
+
 // shard_rollout: the rollouts of a K-sharded solve only (bn_mppi_shard_rollout_async); the tail follows the exchange.
 static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise,
                       bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr, int alt_buffers = 0, bool self_tail = false)
@@ -892,6 +935,9 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     if ((noise == BN_NOISE_PHILOX) != (eps == nullptr))
         return fail(BN_ERR_INVALID, "eps must be NULL exactly when noise == BN_NOISE_PHILOX");
     BN_BIND(h);
+    if (!overlap && g_overlap_owners.load(std::memory_order_relaxed) > 0) {
+        if (int rc = order_behind_foreign_overlap(h, on_stream ? on_stream : h->stream)) return rc;
+    }
 
     bn::SolveParams p = h->p;
     const size_t B = p.B, K = p.K, T = p.T;
@@ -1197,9 +1243,21 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
             (void)hipGetLastError();
             if (busy) mine = false;
         }
+        for (bn_mppi *o : g_handles[h->cfg.device_id]) {   // ... and is every other handle idle?  (see g_handles)
+            if (!mine) break;
+            if (o == h) continue;
+            for (int q = 0; mine && q < std::max(o->n_streams, 1); ++q) {
+                const hipStream_t os = q ? o->xstream[q - 1] : o->stream;
+                if ((q && !os) || os == h->stream) continue;
+                if (hipStreamQuery(os) != hipSuccess) mine = false;
+            }
+        }
+        (void)hipGetLastError();
         const size_t slots_ = h->wave_kernel ? 24 * (size_t)std::max(h->n_cus, 1) : (h->lat_kernel ? (size_t)std::max(h->n_cus, 1) : h->resident_wgs);
         if (mine && 2 * (size_t)h->p.B * (h->p.nblk + 1) > slots_ && !own_device_for_big_overlap(h->cfg.device_id)) mine = false;
         if (mine) owner = h;
+        else if (!owner) g_overlap_owner.erase(h->cfg.device_id);      // (operator[] above created an empty entry)
+        g_overlap_owners.store((int)g_overlap_owner.size(), std::memory_order_relaxed);
     }
     const bn_mppi::BatchRec rec{n, states, eps, noise, eps_ring, eps_stride, false, nullptr};
     const bool replayable = states_where == BN_MEM_DEVICE && noise != BN_NOISE_HOST_KT2;

@@ -474,9 +474,9 @@ __device__ __forceinline__ unsigned long long *flag_ctr(unsigned long long *base
 __device__ __forceinline__ void raise_wait_expired(const SolveParams &p, const unsigned long long *ctr = nullptr, unsigned long long need = 0)
 {
 #ifdef BN_EXPERIMENTS                                  // which wait it was, for the host's message (tools/_repro*.py)
-    if (ctr && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
-        p.err[8] = (int)((ctr - p.flag_part) / kFlagStride); p.err[9] = (int)need;
-        p.err[10] = (int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); p.err[11] = (int)p.solve;
+    if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        p.err[8] = ctr ? (int)((ctr - p.flag_part) / kFlagStride) : -1; p.err[9] = (int)need;
+        p.err[10] = ctr ? (int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1; p.err[11] = (int)p.solve;
         p.err[12] = blockIdx.x; p.err[13] = blockIdx.y; p.err[14] = p.have_prev * 100 + p.overlap * 10 + p.cur_slot; p.err[15] = (int)p.wait_part * 1000 + (int)p.wait_tail;
     }
 #endif

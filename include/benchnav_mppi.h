@@ -192,7 +192,10 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
  * With n >= 3 (and device-resident inputs) the solves of one call alternate between the handle's stream and an internal one and
  * OVERLAP: solve i+1 is dispatched while solve i runs and waits on the device for its predecessor's softmin partials instead of
  * for its kernel's end; results are bit-identical to the one-stream chain (BN_FLAG_NO_OVERLAP turns it off: the switch for a GPU
- * shared with other work).  What is ordered for the caller:
+ * shared with other work).  Several handles in one process: a batch overlaps only while every other handle on the device is idle,
+ * and a launch of another handle that arrives while an overlapped batch is in flight runs behind that batch's end (events on the
+ * device, no host blocking) -- waiting workgroups hold their slots and must not share the device with anybody's launches.
+ * What is ordered for the caller:
  *   - the LAST solve of the call and the tail behind it run on the handle's stream, so work enqueued there afterwards is ordered
  *     behind the batch's final results by the queue itself; the internal stream is not joined back -- its kernels have handed
  *     everything over through device counters by then and end within microseconds (bn_mppi_sync waits for both);

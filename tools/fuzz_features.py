@@ -1,129 +1,9 @@
-"""Differential sweep over the knobs that must NOT change a result: kernel family (auto / role / wave / lat), overlapped launches,
-one or two launches per solve, lean mode, the LDS window, how n dependent solves are cut into calls (batches of any length, single
-solves, getters in between).  Every case runs the same n warm-started solves of B instances on two handles -- the plain one (one
-stream, automatic kernel, one call per solve) and a randomly knobbed one -- and compares costs, weights, U*, X*, the mean
-and the trajectory batch bit for bit.  Geometry, horizon (incl. the slow path), resolution (incl. the validated quotient), noise
-source and arithmetic vary with the seed and are the same on both sides.
-    python tools/fuzz_features.py 0 300"""
+"""Wide one-off run of tests/differential.py's first sweep (kernel family, overlap, lean, window, call cuts: no result may change):
+    python tools/fuzz_features.py 0 6000          FUZZ_BREAK=1: self-test, every case must then report a mismatch"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import numpy as np, torch
-from benchnav_amd import NativeMPPI, _capi
-from benchnav_amd.mppi import _DevArray
-
-
-def case(seed):
-    rng = np.random.default_rng(50_000 + seed)
-    B = int(rng.choice([1, 1, 2, 3, 5, 16, 70]))
-    K = int(rng.choice([64, 100, 257, 1000, 1024, 2049, 4160, 5000, 8192] if B <= 5 else [64, 100, 257, 1024]))
-    T = int(rng.choice([1, 2, 5, 17, 33, 50, 64, 97, 150, 420]))
-    if K * T * B > 3_000_000:
-        T = max(1, 3_000_000 // (K * B))
-    G = int(rng.choice([17, 50, 64, 129, 256]))
-    res = float(rng.choice([0.5, 0.5, 0.25, 0.3, 0.1, 1.0]))
-    x0, y0 = float(rng.choice([0.0, 0.0, -3.5, 1.3])), float(rng.choice([0.0, 0.0, 2.25]))
-    wide = rng.random() < 0.07
-    span = G * res * (1.25 if wide else 1.0)
-    shared = bool(B > 1 and rng.random() < 0.4)
-    maps = (rng.random((1 if shared else B, G, G)) * rng.choice([0.5, 0.95, 1.2])).astype(np.float32)
-    states = np.stack([rng.uniform(x0, x0 + G * res, B), rng.uniform(y0, y0 + G * res, B), rng.uniform(-4, 4, B)], 1).astype(np.float32)
-    goals = np.stack([rng.uniform(x0, x0 + G * res, B), rng.uniform(y0, y0 + G * res, B)], 1).astype(np.float32)
-    noise = str(rng.choice(["philox", "philox", "kt2", "t2k"]))
-    if noise != "philox" and B * K * T > 600_000:
-        noise = "philox"
-    n = int(rng.choice([1, 2, 3, 4, 7, 16, 17, 20, 33]))
-    common = dict(horizon=T, num_samples=K, grid_size=G, resolution=res, x_limits=[x0, x0 + span], y_limits=[y0, y0 + span],
-                  sigmas=[float(rng.choice([0.5, 0.1, 1.5])), float(rng.choice([0.5, 0.25, 2.0]))], lambda_=float(rng.choice([0.5, 0.05, 3.0])),
-                  u_min=[float(rng.choice([0.0, -0.5])), float(rng.choice([-1.0, -0.3]))], u_max=[float(rng.choice([1.0, 0.4])), float(rng.choice([1.0, 2.0, 6.0]))],
-                  dt=float(rng.choice([0.1, 0.1, 0.05, 0.4])), stuck_threshold=float(rng.choice([0.3, 0.0, 0.55])), num_instances=B, shared_map=shared,
-                  seed=int(rng.integers(1, 1 << 30)), reference_order=bool(rng.random() < 0.25))
-    knobs = dict(kernel=str(rng.choice(["auto", "auto", "role", "wave", "lat"])), overlap=bool(rng.random() < 0.7), pipeline=bool(rng.random() < 0.8),
-                 lean=bool(rng.random() < 0.3), lds_window=bool(rng.random() < 0.85), store_controls=bool(rng.random() < 0.3))
-    cuts = []                                               # how the n solves are cut into calls
-    left = n
-    while left:
-        m = int(min(left, rng.choice([1, 1, 2, 3, 5, 16, 20, 33])))
-        cuts.append((m, str(rng.choice(["none", "none", "weights", "sync", "flush", "first_action"]))))
-        left -= m
-    return dict(B=B, K=K, T=T, G=G, maps=maps, states=states, goals=goals, noise=noise, n=n, common=common, knobs=knobs, cuts=cuts, rng=rng)
-
-
-def make(c, **kw):
-    pl = NativeMPPI(**c["common"], **kw)
-    for b in range(c["B"] if not c["common"]["shared_map"] else 1):
-        pl.set_map(c["maps"][b], b if not c["common"]["shared_map"] else -1)
-    for b in range(c["B"]):
-        pl.set_goal(c["goals"][b], b)
-    return pl
-
-
-def outputs(pl, c, lean):
-    pl.sync()
-    B, T, K = c["B"], c["T"], c["K"]
-    xs = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_XSTAR)[0], (B, T + 1, 3)), device="cuda").cpu().numpy()
-    us = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_USTAR)[0], (B, T, 2)), device="cuda").cpu().numpy()
-    out = {"xstar": xs, "ustar": us}
-    for b in sorted({0, B // 2, B - 1}):
-        out[f"cost{b}"] = pl.costs(b); out[f"w{b}"] = pl.weights(b); out[f"mean{b}"] = pl.get_mean(b)
-        if not lean:
-            out[f"X{b}"] = pl.states(b)
-    return out
-
-
-def run(seed):
-    c = case(seed)
-    B, K, T, n = c["B"], c["K"], c["T"], c["n"]
-    st = torch.from_numpy(c["states"]).cuda()
-    kind, eps, ring, stride = _capi.BN_NOISE_PHILOX, None, 1, 0
-    if c["noise"] != "philox":
-        ring = min(n, 3)
-        shape = (ring, B, K, T, 2) if c["noise"] == "kt2" else (ring, B, T, 2, K)
-        eps = torch.from_numpy(c["rng"].standard_normal(shape).astype(np.float32)).cuda()
-        kind = _capi.BN_NOISE_DEVICE_KT2 if c["noise"] == "kt2" else _capi.BN_NOISE_DEVICE_T2K
-        stride = eps[0].numel()
-    torch.cuda.synchronize()
-    eptr = eps.data_ptr() if eps is not None else None
-    try:
-        plain = make(c, overlap=False)
-    except Exception as e:                                      # noqa: BLE001
-        return "skip: " + str(e)[:80]
-    with plain:
-        for i in range(n):
-            e_i = None if eps is None else eptr + 4 * stride * (i % ring)
-            plain.solve_async_device(st.data_ptr(), e_i, kind)
-        want = outputs(plain, c, False)
-    if os.environ.get("FUZZ_BREAK"):                           # self-test of the sweep: a different Philox seed / goal must show up as mismatches
-        c["common"] = dict(c["common"], seed=c["common"]["seed"] + 1); c["goals"] = c["goals"] + 0.25
-    try:
-        knobbed = make(c, **c["knobs"])
-    except Exception as e:                                      # noqa: BLE001 -- a forced kernel that this geometry cannot run
-        return "skip: " + str(e)[:80]
-    with knobbed as pl:
-        done = 0
-        for m, then in c["cuts"]:
-            # the ring position follows the solve count: batches start where the previous call stopped
-            if eps is None:
-                pl.solve_n_async_device(m, st.data_ptr()) if m > 1 else pl.solve_async_device(st.data_ptr())
-            else:
-                for j in range(m) if (done % ring) else [None]:
-                    if j is None:
-                        pl.solve_n_async_device(m, st.data_ptr(), eptr, kind, ring, stride)
-                    else:
-                        pl.solve_async_device(st.data_ptr(), eptr + 4 * stride * ((done + j) % ring), kind)
-            done += m
-            if then == "weights": pl.weights(0)
-            elif then == "sync": pl.sync()
-            elif then == "flush": pl.flush()
-            elif then == "first_action": pl.first_action(B - 1)
-        got = outputs(pl, c, c["knobs"]["lean"])
-        rec = pl.recovery_count()
-    for k, v in got.items():
-        if not np.array_equal(v, want[k], equal_nan=True):
-            d = np.abs(v.astype(np.float64) - want[k]).max() if np.isfinite(v).all() and np.isfinite(want[k]).all() else float("nan")
-            return f"MISMATCH {k} max|d|={d:.3g}"
-    return "ok" + (f" (recoveries {rec})" if rec else "")
-
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from differential import case, run
 
 if __name__ == "__main__":
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
