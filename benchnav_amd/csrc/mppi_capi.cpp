@@ -136,6 +136,7 @@ struct bn_mppi {
     int n_maps = 1;
     uint64_t solves = 0;
     bool map_set = false, goal_set = false;
+    uint64_t map_epoch = 0, map_epoch_at_solve = 0;   // set_map calls so far / at the latest solve: a re-roll needs the map that solve saw
     // Pipelined mode (K <= 2048): one launch per solve.  The launch of solve i merges solve i-1's
     // per-block statistics in every rollout workgroup (warm start) and carries an aux workgroup that
     // writes solve i-1's tail (U*, X*, weights).  `tail_pending` = the latest solve's tail has not been
@@ -342,6 +343,11 @@ int recover_overlap(bn_mppi *h)
         if (h->xstream[q]) BN_HIP(hipStreamSynchronize(h->xstream[q]));
     BN_HIP(hipStreamSynchronize(h->stream));
     BN_HIP(hipMemset(h->d_flags, 0, ((kSlots + 1) * (size_t)h->p.B + 3) * bn::kFlagStride * sizeof(unsigned long long)));      // counters and the device error word
+    // ... and the ticket counters of the ticket merge (K > 4096, sampled slip): they are per instance, not per launch -- a launch that
+    // gave up waiting and the starved predecessor it gave up on draw from them at the same time, and the merger's reset to zero races
+    // with the other launch's increments.  Left non-zero they make the re-run's first launch merge before its rows are complete: a
+    // repair with wrong results (round 4, tests/differential.py `ops` seed 2681: half of the natural expiries of that configuration).
+    if (h->d_ticket) BN_HIP(hipMemset(h->d_ticket, 0, (size_t)h->p.B * 65 * 4));
     for (int q = 0; q < kSlots; ++q) h->pub[q] = 0;
     h->tails = 0;
     h->prev_published = false;
@@ -829,6 +835,7 @@ int bn_mppi_set_map(bn_mppi_t *h, int32_t instance, const float *risk, bn_mem_ki
     BN_HIP(hipStreamSynchronize(h->stream));
     for (int m = lo; m < hi; ++m) BN_HIP(hipMemcpy(h->d_map + (size_t)m * h->p.G * h->p.G, risk, bytes, kind));
     h->map_set = true;
+    h->map_epoch += 1;
     return BN_OK;
 }
 
@@ -941,6 +948,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
 
     bn::SolveParams p = h->p;
     const size_t B = p.B, K = p.K, T = p.T;
+    h->map_epoch_at_solve = h->map_epoch;
     if (states_where == BN_MEM_DEVICE) {
         p.state = states;
     } else {
@@ -1255,6 +1263,13 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         (void)hipGetLastError();
         const size_t slots_ = h->wave_kernel ? 24 * (size_t)std::max(h->n_cus, 1) : (h->lat_kernel ? (size_t)std::max(h->n_cus, 1) : h->resident_wgs);
         if (mine && 2 * (size_t)h->p.B * (h->p.nblk + 1) > slots_ && !own_device_for_big_overlap(h->cfg.device_id)) mine = false;
+        // A launch that needs well over one residency round by itself is never fully placed while it runs: its successor's waiting
+        // workgroups compete with its OWN remaining ones for every slot that frees up, whatever the host orders.  Up to a quarter over
+        // (64 instances of K = 1024: 1088 workgroups on 1024 slots; 70: 1190) the remainder is placed when the first round drains and
+        // nothing has ever expired (tens of thousands of launches, fresh processes included); at one and a half rounds (3 instances of
+        // K = 8192 at one workgroup per CU: 387 on 256) the first batch of a fresh process expired every time (round 4,
+        // tests/differential.py `ops` seed 2681).  Such batches run on one stream.
+        if (mine && 4 * (size_t)h->p.B * (h->p.nblk + 1) > 5 * slots_) mine = false;
         if (mine) owner = h;
         else if (!owner) g_overlap_owner.erase(h->cfg.device_id);      // (operator[] above created an empty entry)
         g_overlap_owners.store((int)g_overlap_owner.size(), std::memory_order_relaxed);
@@ -1347,7 +1362,11 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
             }
             return BN_OK;
         };
-        if (crowd && !h->replaying && n >= 3 && i < 3) {
+        // Only launches that exceed one residency round by THEMSELVES can be starved for good (a waiting launch of at most one round
+        // leaves its predecessor's running workgroups to finish and free what the rest of it needs): two launches that merely do not
+        // fit side by side -- 256 instances on the one-wave kernel, K = 16384 -- skip the hand-over.
+        const bool over = (size_t)h->p.B * (h->p.nblk + 1) > slots;
+        if (over && !h->replaying && n >= 3 && i < 3) {
             if (i == 0) {
                 stamp = (int)(h->solves & 0x3fffffff) + 1;
                 for (int w = 4; w < 8; ++w) __atomic_store_n(&h->h_err[w], 0, __ATOMIC_RELEASE);
@@ -1662,6 +1681,7 @@ int bn_mppi_debug_expire_wait(bn_mppi_t *h)
     BN_HIP(hipMemset(h->d_w, 0xff, B * K * 4));
     BN_HIP(hipMemset(h->d_cost_out, 0xff, B * K * 4));
     if (h->d_X) BN_HIP(hipMemset(h->d_X, 0xff, B * (T + 1) * 3 * (size_t)h->p.Kp * 4));
+    if (h->d_ticket) BN_HIP(hipMemset(h->d_ticket, 0x01, B * 65 * 4));      // what two launches drawing tickets at once leave behind (recover_overlap)
     if (h->d_ep_states && h->ep_len > 0) {
         BN_HIP(hipMemset(h->d_ep_states, 0xff, (size_t)(h->ep_len + 1) * B * 3 * 4));
         BN_HIP(hipMemset(h->d_ep_reward, 0xff, (size_t)h->ep_len * B * 4));
@@ -1704,6 +1724,10 @@ static int reroll_rows(bn_mppi_t *h, int32_t instance, const int *idx_device, in
     if (h->p.slip_on) return fail(BN_ERR_INVALID, "re-rolling is not available in sampled-slip mode");
     if (h->solves == 0) return fail(BN_ERR_STATE, "no solve has run");
     if (h->shard_pending) return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
+    // The rows are rolled out again on the map as it is NOW: after a bn_mppi_set_map they would not be the latest solve's rollouts
+    // (the reference's get_top_samples returns the batch forward() stored, mppi.py:221-240) -- refuse instead of answering for another map.
+    if (h->map_epoch != h->map_epoch_at_solve)
+        return fail(BN_ERR_STATE, "the map changed since the latest solve: its rollouts cannot be regenerated (read them before bn_mppi_set_map, or solve again)");
     if (int rc = flush_tail(h)) return rc;
     bn::SolveParams p = h->p;
     const int cur = (int)((h->solves - 1) % kSlots);

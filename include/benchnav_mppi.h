@@ -336,7 +336,9 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
 /* Rows of the LATEST solve's _state_seq_batch regenerated on the device (works in every mode but sampled-slip; it is how
  * lean mode serves get_top_samples, mppi.py:232-238): rollouts idx_device[0..n) (NULL: rollouts 0..n-1) -> out_device
  * (n,T+1,3), bit-identical to the rows a full-API solve stores (same noise, mean, start state, device functions).
- * Writes the pending tail first; with injected noise the caller's eps block of that solve must still be alive. */
+ * Writes the pending tail first; with injected noise the caller's eps block of that solve must still be alive.
+ * BN_ERR_STATE after a bn_mppi_set_map that followed the latest solve: the rows would be rolled out on the NEW map, not be that
+ * solve's rollouts (in lean mode this also applies to bn_mppi_get_states / bn_mppi_get_top_samples). */
 int bn_mppi_reroll_async(bn_mppi_t *h, int32_t instance, const int32_t *idx_device, int32_t n, float *out_device);
 
 /* Zero-copy access to a library-owned device buffer (layouts in bn_buffer_id). */

@@ -241,3 +241,80 @@ def pair(seed):
     return "ok" + (f" (recoveries {rec})" if rec else "")
 
 
+
+
+def ops(seed):
+    """Operation sequences: batches and single solves with setters (goal, mean, map), getters (top samples, controls) and -- on the
+    knobbed side only -- the expired-wait test hook at random points: the journal's re-run has to reproduce, through whatever came in
+    between, what a handle that never overlapped computes.  Philox noise; lean handles re-roll their top samples."""
+    c = case(seed + 300_000)
+    rng = np.random.default_rng(93_000 + seed)
+    c["noise"] = "philox"
+    B, K, T, G = c["B"], c["K"], c["T"], c["G"]
+    if B > 16:
+        return "skip: big"
+    st_all = [c["states"]] + [(c["states"] + rng.normal(0, 0.3, c["states"].shape)).astype(np.float32) for _ in range(2)]
+    goals2 = (c["goals"] + rng.normal(0, 2.0, c["goals"].shape)).astype(np.float32)
+    mean2 = (rng.standard_normal((T, 2)) * 0.3).astype(np.float32)
+    map2 = np.clip(c["maps"][0] * 0.5 + 0.2, 0, 1).astype(np.float32)
+    script = []
+    for _ in range(int(rng.integers(2, 9))):
+        kind = str(rng.choice(["batch", "batch", "batch", "single", "goal", "mean", "map", "top", "state", "expire", "expire", "sync"]))
+        script.append((kind, int(rng.choice([2, 3, 4, 5, 7, 16, 20])), int(rng.integers(0, B)), int(rng.integers(0, 3))))
+    script.append(("batch", int(rng.choice([3, 5, 17])), 0, 0))
+    tops = [[], []]
+    outs = []
+    cur = torch.cuda.current_stream().cuda_stream            # the handles run on torch's stream: the 'state' copies below are stream-ordered
+    for side, knobs in enumerate((dict(overlap=False), c["knobs"])):
+        try:
+            pl = make(c, stream=cur, **knobs)
+        except Exception as e:                                  # noqa: BLE001
+            return "skip: " + str(e)[:60]
+        with pl:
+            st = torch.from_numpy(st_all[0].copy()).cuda(); torch.cuda.synchronize()
+            solves = 0
+            last = ""
+            fresh_map = False
+            for kind, m, b, which in script:
+                prev, last = last, kind
+                if kind == "batch":
+                    if side == 0:
+                        for _ in range(m): pl.solve_async_device(st.data_ptr())
+                    else:
+                        pl.solve_n_async_device(m, st.data_ptr())
+                    solves += m; fresh_map = False
+                elif kind == "single":
+                    pl.solve_async_device(st.data_ptr()); solves += 1; fresh_map = False
+                elif kind == "goal":
+                    pl.set_goal(goals2[b], b)
+                elif kind == "mean":
+                    pl.set_mean(mean2, b)
+                elif kind == "map":
+                    pl.set_map(map2, -1 if c["common"]["shared_map"] else b); fresh_map = True
+                elif kind == "top" and solves and not fresh_map:    # (a lean handle refuses to re-roll on a map its solve did not see)
+                    tops[side].append(pl.top_samples(min(5, K), b))
+                elif kind == "state":
+                    # the caller rewrites its state buffer in stream order (allowed: the journal keeps what each batch was given)
+                    st.copy_(torch.from_numpy(st_all[which]).cuda(), non_blocking=True)
+                elif kind == "expire" and side == 1 and prev == "batch":
+                    # (the hook stands for an expiry in the batch just enqueued; with nothing journalled -- the knobbed handle did not
+                    # overlap -- it leaves NaN patterns nothing can repair: not a case)
+                    _capi.check(pl._lib.bn_mppi_debug_expire_wait(pl._h))
+                    try:
+                        pl.sync()
+                    except Exception as e:                      # noqa: BLE001
+                        if "cannot be re-run" in str(e):
+                            return "skip: nothing journalled"
+                        raise
+                elif kind == "sync":
+                    pl.sync()
+            outs.append(outputs(pl, c, side == 1 and c["knobs"]["lean"]))
+    diff = [k for k, v in outs[1].items() if not np.array_equal(v, outs[0][k], equal_nan=True)]
+    if diff:
+        return "MISMATCH ops " + ",".join(diff)
+    if len(tops[0]) != len(tops[1]):
+        return "MISMATCH ops top count"
+    for (s0, w0), (s1, w1) in zip(*tops):
+        if not (np.array_equal(s0, s1, equal_nan=True) and np.array_equal(w0, w1, equal_nan=True)):
+            return "MISMATCH ops top samples"
+    return "ok"

@@ -140,6 +140,35 @@ def test_interleaved_grid_gives_every_instance_its_own_result(B):
             assert np.array_equal(batched[b][j], alone[j]), (b, j)
 
 
+def test_lean_refuses_to_regenerate_rollouts_on_a_map_the_solve_did_not_see():
+    """Lean mode keeps no trajectory batch: get_top_samples re-rolls the winners (same noise, mean, start state) -- on the map as it is
+    at that moment.  After a set_map that followed the solve that would be another map's rollouts (tests/differential.py `ops`, seeds
+    12 and 33: a full handle returns the stored batch, mppi.py:221-240); the library says so instead."""
+    from benchnav_amd import NativeMPPI, synth
+    from benchnav_amd._capi import BenchnavError
+    inst = synth.make_instance(64, seed=3)
+    other = np.clip(inst.risk.numpy() * 0.5 + 0.2, 0, 1).astype(np.float32)
+    res = {}
+    for lean in (False, True):
+        with NativeMPPI(horizon=20, num_samples=256, grid_size=64, resolution=0.5, lean=lean, seed=9) as pl:
+            pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+            pl.solve(inst.start.numpy()[None])
+            res[lean, "before"] = pl.top_samples(4)
+            pl.set_map(other)
+            if lean:
+                with pytest.raises(BenchnavError, match="map changed since the latest solve"):
+                    pl.top_samples(4)
+            else:
+                res[lean, "after"] = pl.top_samples(4)                 # the stored batch: unchanged by the new map
+            pl.solve(inst.start.numpy()[None])
+            res[lean, "again"] = pl.top_samples(4)
+    for key in ("before", "again"):
+        for a, b in zip(res[False, key], res[True, key]):
+            assert np.array_equal(a, b), key
+    for a, b in zip(res[False, "before"], res[False, "after"]):
+        assert np.array_equal(a, b)
+
+
 def test_failed_create_frees_everything_it_allocated():
     """bn_mppi_create used to return straight out of its late allocations, leaking the handle and every earlier buffer
     (VERDICT r1 item 8).  A handle that cannot be allocated must leave the device's free memory where it was."""

@@ -1,13 +1,13 @@
 """Wide one-off run of tests/differential.py's other sweeps -- device-side episodes, sampled slip, pairs of planners alive at once:
-    python tools/fuzz_features2.py 0 1500 [episode,sampled,pair]"""
+    python tools/fuzz_features2.py 0 1500 [episode,sampled,pair,ops]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from differential import episode, sampled, pair
+from differential import episode, sampled, pair, ops
 
 if __name__ == "__main__":
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
-    which = sys.argv[3].split(",") if len(sys.argv) > 3 else ["episode", "sampled", "pair"]
+    which = sys.argv[3].split(",") if len(sys.argv) > 3 else ["episode", "sampled", "pair", "ops"]
     for name in which:
         fn = globals()[name]
         tally = {}
