@@ -633,6 +633,9 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.ustar = h->d_ustar; p.xstar = h->d_xstar; p.stats = h->d_stats; p.mean_used = h->d_mean_used;
     // every rollout workgroup re-merges the previous solve's nblk partials: only worth it while they are few
     p.slip_on = (cfg->flags & BN_FLAG_SAMPLED_SLIP) ? 1 : 0;
+    // (the fused sampled-slip kernel has its own, larger LDS layout: what an overlapped batch may count on being resident -- the
+    // residency rules of bn_mppi_solve_n_async -- is that kernel's figure, not the role kernel's)
+    if (p.slip_on && bn::sampled_fused(p)) h->resident_wgs = bn::sampled_resident_per_cu(p) * (size_t)h->n_cus;
     h->pipelined = !h->slow_path && !(cfg->flags & BN_FLAG_NO_PIPELINE) && p.nblk <= kPipelinedMaxBlocks && !p.slip_on;
     // throughput kernel: launches with more workgroups than the role kernel keeps resident in one round (4 per CU)
     h->wave_kernel = h->pipelined && want_wave;
@@ -1337,7 +1340,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         const int q = idle ? (n - 1 - i) % S : (i == n - 1 ? 0 : i % S);
         // A long batch ends with its own tail (see below): on the latency kernel it rides in the last launch as a second aux workgroup.
         const bool own_tail = i == n - 1 && n >= kEagerTailMinBatch && exp_self_tail;
-        // Launches big enough to crowd each other out (more than one residency round between two of them): a launch whose workgroups
+        // A launch that exceeds one residency round (`over` below; up to 1.25 rounds overlap at all, see `mine`): a launch whose workgroups
         // wait for partials holds slots, and the dispatcher does not share freed slots fairly between two queues -- a successor that
         // becomes eligible while its predecessor still has workgroups to place can take every slot and starve it until the bounded waits
         // expire.  In the steady state that cannot happen: launch i+1 becomes eligible when launch i-1 completes, a whole kernel after

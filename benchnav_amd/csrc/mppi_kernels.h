@@ -157,6 +157,7 @@ hipError_t launch_finish(const SolveParams &p, hipStream_t s);
 // rows idx[0..n) (nullptr: 0..n) of instance b's trajectory batch of the solve described by p (p.solve, p.eps, p.state, p.mean_used)
 hipError_t launch_reroll(const SolveParams &p, EpsMode mode, int b, const int *idx, int n, float *out_n_T1_3, hipStream_t s);
 hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s);
+size_t sampled_resident_per_cu(const SolveParams &p);   // workgroups of that kernel per CU (LDS, wave slots)
 bool sampled_fused(const SolveParams &p);   // the sampled launch merges by ticket and carries the previous tail (LDS-window variant)
 hipError_t launch_dwa(const SolveParams &p, const float *actions, const float *stage_goal, int NA, float *Xall, float *cost,
                       float *w, int *best, float *best_states, float *best_action, hipStream_t s);

@@ -316,6 +316,13 @@ __global__ void philox_slip_kernel(float *__restrict__ zt, float *__restrict__ z
 
 }  // namespace
 
+size_t sampled_resident_per_cu(const SolveParams &p)
+{
+    // workgroups of the fused sampled-slip kernel one CU holds at once: LDS (its slot rows and draw tiles) and 32 wave slots
+    const size_t need = sizeof(float) * sampled_lds_floats(p.T, p.WN);
+    return std::max<size_t>(1, std::min<size_t>(160 * 1024 / std::max<size_t>(need, 1), 32 / kSampledWaves));
+}
+
 bool sampled_fused(const SolveParams &p)
 {
     // the multi-wave kernel needs the LDS window and room for its tiles; its LDS also holds the aux tail / merge scratch

@@ -122,8 +122,11 @@ def run(seed):
             elif then == "sync": pl.sync()
             elif then == "flush": pl.flush()
             elif then == "first_action": pl.first_action(B - 1)
+        fa = np.stack([pl.first_action(b) for b in range(B)])      # the mail the tail posts: U*[0] of the latest solve, per instance
         got = outputs(pl, c, c["knobs"]["lean"])
         rec = pl.recovery_count()
+        if not np.array_equal(fa, got["ustar"][:, 0, :], equal_nan=True):
+            return "MISMATCH first_action vs ustar[:, 0]"
     for k, v in got.items():
         if not np.array_equal(v, want[k], equal_nan=True):
             d = np.abs(v.astype(np.float64) - want[k]).max() if np.isfinite(v).all() and np.isfinite(want[k]).all() else float("nan")
@@ -146,6 +149,9 @@ def episode(seed):
     n_maps = 1 if c["common"]["shared_map"] else c["B"]
     lm = np.clip(c["maps"], 0, 1).astype(np.float32)
     ls = (rng.random((n_maps, c["G"], c["G"])) * 0.1).astype(np.float32)
+    thr, freeze = float(rng.choice([1.0, 0.3, 5.0, 20.0])), bool(rng.random() < 0.5)
+    zdev = torch.from_numpy(rng.standard_normal((steps, c["B"])).astype(np.float32)).cuda() if rng.random() < 0.5 else None   # injected slip draws of the environment
+    torch.cuda.synchronize()
     logs = []
     for knobs in (dict(overlap=False), dict(kernel=c["knobs"]["kernel"], overlap=True, lds_window=c["knobs"]["lds_window"])):
         try:
@@ -154,8 +160,8 @@ def episode(seed):
             return "skip: " + str(e)[:60]
         with pl:
             try:
-                pl.env_attach(lm, ls, goal_threshold=float(rng.choice([1.0, 0.3])) if False else 1.0, delta_t=c["common"]["dt"], seed=7)
-                pl.episode(steps, c["states"], wait=False)
+                pl.env_attach(lm, ls, goal_threshold=thr, delta_t=c["common"]["dt"], seed=7, freeze_on_goal=freeze)
+                pl.episode(steps, c["states"], z_device_ptr=(zdev.data_ptr() if zdev is not None else None), wait=False)
                 logs.append(pl.episode_log())
             except Exception as e:                              # noqa: BLE001
                 return "skip: " + str(e)[:60]
