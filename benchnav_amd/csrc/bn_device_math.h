@@ -62,8 +62,31 @@ __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
 // test oracle (bn_rotate_spec).  Scalar statement of what the packed stream computes:
 //   d2 = d*d; cd = fma(d2, fma(d2, fma(d2, C6, C4), C2), 1); sp = fma(d2, fma(d2, fma(d2, S7, S5), S3), 1); sd = d*sp;
 //   cs' = fma(cs, cd, -(sn*sd)); sn' = fma(sn, cd, cs*sd)
-__device__ __forceinline__ void rotate_spec(float &cs, float &sn, float d)
+template <bool ONEBLOCK = false>
+__device__ __forceinline__ void rotate_spec(float &cs, float &sn, float d, v2f c0_pinned = v2f{0.0f, 0.0f})
 {
+#ifdef BN_CHAIN_ASM2
+    if (ONEBLOCK) {
+        // The latency kernel's chain wave: the seven instructions below as the compiler emits them for the statements that
+        // follow, in ONE asm block -- between the packed multiply (op_sel_hi[0] = 1) and the asm of the last FMA the hazard
+        // recogniser put an s_nop (trav_window has the story).  v[124:127]: scratch; v127 is read as the unused half of a pair.
+        v2f h = {cs, sn};
+        const v2f c0 = c0_pinned;                      // {1/24, 1/120}, in vector registers the caller keeps (Win::c0_v)
+        const v2f c1 = {-0.00138888892251998186f, -0.000198412701138295233f};
+        const v2f c2 = {-0.5f, -0.16666667163372040f};
+        asm("v_mul_f32 v126, %1, %1\n\t"
+            "v_pk_fma_f32 v[124:125], v[126:127], %2, %3 op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 v[124:125], v[126:127], v[124:125], %4 op_sel_hi:[0,1,1]\n\t"
+            "v_pk_fma_f32 v[124:125], v[126:127], v[124:125], 1.0 op_sel_hi:[0,1,0]\n\t"
+            "v_mul_f32 v126, %1, v125\n\t"
+            "v_pk_mul_f32 v[126:127], %0, v[126:127] op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %0, v[124:125], v[126:127] op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_lo:[0,0,1]"
+            : "+v"(h) : "v"(d), "s"(c1), "v"(c0), "s"(c2) : "v124", "v125", "v126", "v127");
+        cs = h.x;
+        sn = h.y;
+        return;
+    }
+#endif
     const float d2 = d * d;
     const v2f dd = {d2, d2};
     v2f pq = __builtin_elementwise_fma(dd, v2f{-0.00138888892251998186f, -0.000198412701138295233f}, v2f{0.0416666679084300995f, 0.00833333376795053482f});

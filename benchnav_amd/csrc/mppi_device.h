@@ -3,6 +3,15 @@
 // Everything here has internal linkage (anonymous namespace); each .hip file instantiates what it launches.
 #pragma once
 #include "mppi_kernels.h"
+// Round 4's cut of the latency kernel's chain wave and producers (on; -DBN_VAR_R3_CHAIN builds the previous one for A/B runs,
+// tools/variant_ab.py): BN_CHAIN_ASM2 -- the gather's address arithmetic and the rotation as one asm block each (no hazard
+// wait states around them), BN_RING_IMM -- ring slots and control rows through one address register per chunk and immediate
+// offsets, BN_PREDRAW -- the horizon's Philox noise drawn into the control tile while the predecessor's rows are still on their way.
+#ifndef BN_VAR_R3_CHAIN
+#define BN_CHAIN_ASM2 1
+#define BN_RING_IMM 1
+#define BN_PREDRAW 1
+#endif
 #include "bn_device_math.h"
 
 #include <math.h>
@@ -71,7 +80,10 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 //   kGeoPow2Origin0  additionally origin == 0, so the subtraction is the identity
 enum Geo : int { kGeoGeneral = 0, kGeoPow2 = 1, kGeoPow2Origin0 = 2 };
 
-struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; int wn; };   // window origin (cells), as floats, edge, edge-1, edge
+struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; int wn;
+             // the latency kernel's chain wave (BN_CHAIN_ASM2): constants it keeps in vector registers of its own -- left to the compiler
+             // they are re-materialised from scalar registers in every chunk
+             float xhi_v, yhi_v; v2f c0_v; };   // window origin (cells), as floats, edge, edge-1, edge
 
 // Which workgroup of which instance this is (see rollout_grid): rollout workgroup `blk` of instance `b`, or the aux
 // workgroup of instance `b` (tail of the previous solve).  Rows past the instances hold the aux workgroups, so they are
@@ -204,7 +216,30 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
     } else {
         q = quotient_general(p, xy - v2f{p.x0, p.y0}) + nw;
     }
-    if (ASMIDX == 1) {
+#ifdef BN_CHAIN_ASM2
+    if (ASMIDX == 2 && GEO != kGeoGeneral) {
+        // The latency kernel's chain wave (ASMIDX = 2; the tail's X* rollout keeps ASMIDX = 1 below: fixed registers at the top of
+        // a 128-register budget would cost the role kernel, whose aux workgroup runs that tail, its occupancy).  The same five instructions -- quotient (packed FMA), floor-and-convert x 2, row * WN + col, byte address -- as ONE asm
+        // block whose only result is consumed by the LDS read.  Why: LLVM's hazard recogniser (gfx940+ "dst_sel forwarding") puts
+        // an s_nop between (a) any VALU consumer and an inline asm that defines its operand and (b) an inline asm and a packed
+        // instruction with op_sel_hi[0] = 1 that defines one of its operands (the bit shares its position with VOP3's dst op_sel:
+        // a false positive for VOP3P).  The old cut -- packed FMA | asm(cvt, cvt, mad) | shift-add -- paid both, two issue slots
+        // of the chain wave per step.  Inside one block there is no hazard to assume, and a DS consumer is not a VALU consumer.
+        // v126 / v127: scratch (the halves of a 64-bit asm operand cannot be named, so the quotient lives in fixed registers).
+        typedef __attribute__((address_space(3))) const float lds_cf;
+        const unsigned base = (unsigned)(uintptr_t)(lds_cf *)win;
+        const v2f xyo = GEO == kGeoPow2Origin0 ? xy : xy - v2f{p.x0, p.y0};
+        unsigned addr;
+        asm("v_pk_fma_f32 v[126:127], %1, %2, %3\n\t"
+            "v_cvt_flr_i32_f32 v126, v126\n\t"
+            "v_cvt_flr_i32_f32 v127, v127\n\t"
+            "v_mad_u32_u24 v126, v127, %4, v126\n\t"
+            "v_lshl_add_u32 %0, v126, 2, %5"
+            : "=v"(addr) : "v"(xyo), "s"(ir), "v"(nw), "s"(w.wn), "s"(base) : "v126", "v127");
+        return *(lds_cf *)(uintptr_t)addr;
+    }
+#endif
+    if (ASMIDX >= 1) {
         // The latency kernel's chain wave: floor-and-convert in one instruction, row * WN + col as one v_mad_u32_u24 (left to itself
         // the compiler spreads the *4 of the byte address over both terms).  Same integers.  8.65 -> 8.57 us per dependent solve;
         // NOT for the role kernel (64 instances: +3 %): the compiler pads both ends of an asm block with a wait state and cannot
@@ -280,14 +315,19 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     const v2f pos = __builtin_elementwise_fma(v2f{c.trav, c.trav}, c.G, v2f{c.x, c.y});   // :86-87, x and y in lockstep
     xn = pos.x;
     yn = pos.y;
+#ifdef BN_CHAIN_ASM2
+    c.x = clampf(xn, p.x0, ASMIDX == 2 ? w.xhi_v : p.x_hi);            // :93
+    c.y = clampf(yn, p.y0, ASMIDX == 2 ? w.yhi_v : p.y_hi);            // :94
+#else
     c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
     c.y = clampf(yn, p.y0, p.y_hi);                                    // :94
+#endif
     if (BN_ABLATE & 32) { c.trav = 0.5f + 0.001f * c.x; } else
     c.trav = LDSWIN ? trav_window<GEO, ASMIDX>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
     __builtin_amdgcn_sched_barrier(0);
     if (THETA) tn = theta_step(c.th, dth, FIRST); else tn = dth;
     if (BN_ABLATE & 16) { c.sn = c.sn * 0.5f + dth; c.cs = 1.0f - c.sn; } else
-    rotate_spec(c.cs, c.sn, dth);
+    rotate_spec<ASMIDX == 2>(c.cs, c.sn, dth, w.c0_v);
     if (PREP) chain_prepare(p, c, u0n, u1n);
 }
 

@@ -402,7 +402,8 @@ size_t lat_lds_bytes(const SolveParams &p)
     // [ ring (T + 1) x 64 x float4 | fin 5 x 64 | e 64 | progress 4 | window | mean 2T | mean*inv_var 2T | control tile 2T x 65 ]
     if (p.WN <= 0) return 0;
     const size_t wcap = (size_t)p.WN + 2 * (size_t)p.spec_extra;
-    const size_t own = ((size_t)p.T + 1) * 256 + 5 * 64 + 64 + 8 + wcap * wcap + 4 * (size_t)p.T + 2 * (size_t)p.T * kUPad;
+    // (+ 2 x kChunk rows of slack behind the tile: the chain wave reads the controls of "the next chunk" with immediate offsets)
+    const size_t own = ((size_t)p.T + 1) * 256 + 5 * 64 + 64 + 8 + wcap * wcap + 4 * (size_t)p.T + 2 * ((size_t)p.T + 2 * kChunk) * kUPad;
     const size_t bytes = std::max(sizeof(float) * own, finish_lds_bytes(p) + 256);      // the aux workgroup runs finish_body in the same LDS
     return bytes <= 160 * 1024 ? bytes : 0;
 }
