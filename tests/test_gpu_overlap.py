@@ -33,8 +33,15 @@ def _outputs(pl, B, T):
                                                 (1024, 50, 1, "philox", False, 3),
                                                 # the ticket path (K > 4096: merge by the last workgroup, counted in for the overlapped successor)
                                                 (5000, 50, 1, "philox", False, 12), (16384, 100, 1, "philox", False, 7), (8192, 33, 2, "kt2", True, 9),
-                                                (4160, 20, 3, "t2k", False, 16)],
-                         ids=["c2", "c2-B3-lean", "ragged-kt2", "K2048-t2k", "small-B5", "T1", "n3", "ticket-ref5000", "ticket-c5", "ticket-B2-lean", "ticket-B3-n16"])
+                                                (4160, 20, 3, "t2k", False, 16),
+                                                # the edges of the pre-drawn noise (fast prologue, Philox: step pairs behind chunks 0 and 1 are drawn into the
+                                                # tile before the predecessor's rows arrive): no pair, half a pair, ragged chunks, the last horizon of the fast
+                                                # prologue (2T = 128) and the first one behind it
+                                                (256, 8, 1, "philox", False, 12), (256, 9, 2, "philox", False, 12), (320, 11, 1, "philox", False, 12),
+                                                (256, 13, 1, "philox", True, 12), (256, 63, 1, "philox", False, 8), (256, 64, 1, "philox", False, 8),
+                                                (256, 65, 1, "philox", False, 8)],
+                         ids=["c2", "c2-B3-lean", "ragged-kt2", "K2048-t2k", "small-B5", "T1", "n3", "ticket-ref5000", "ticket-c5", "ticket-B2-lean", "ticket-B3-n16",
+                              "predraw-T8", "predraw-T9-B2", "predraw-T11", "predraw-T13-lean", "predraw-T63", "predraw-T64", "predraw-T65"])
 def test_overlapped_chain_equals_one_stream_chain(K, T, B, noise, lean, n):
     import torch
     from benchnav_amd import _capi, synth
