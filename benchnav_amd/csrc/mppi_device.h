@@ -28,7 +28,8 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 // 1 skip fp64 accumulation, 2 skip X stores, 3 skip control tile + control cost, 4 skip sincos,
 // 5 skip the gather, 6 skip the heading wrap.  Latency kernel only (tools/build_variant_fast.py <name> -DBN_ABLATE=..., timed with
 // BN_TOOL_LIB=<name> tools/region_overhead.py): 7 no ring writes, 9 consumers A and B skip their loops, 10 producers produce nothing,
-// 13 consumer A alone, 14 consumer B alone, 15 the position rows' wave, 16 consumer B only waits for the chain's end.
+// 13 consumer A alone, 14 consumer B alone, 15 the position rows' wave, 16 consumer B only waits for the chain's end,
+// 17 consumer B starts its loop when the chain is through (tools/stamps_blog.py then shows its pace with every slot there).
 #ifndef BN_ABLATE
 #define BN_ABLATE 0
 #endif
