@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from benchnav_amd import build as _b
+if os.environ.get("BN_TOOL_LIB", "main") != "main":                     # a variant built by tools/build_variant_fast.py <name>
+    _b.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_ablate", "lib_%s.so" % os.environ["BN_TOOL_LIB"])
 from benchnav_amd import NativeMPPI, synth
 G, K, T = 256, 1024, 50
 cases = [(int(x), bool(int(y))) for x, y in (c.split(":") for c in os.environ.get("BN_CASES", "1:1,1:0,8:1,8:0,64:1,64:0").split(","))]
