@@ -190,7 +190,10 @@ __device__ __forceinline__ u32x4 philox4x32(u32x4 c, uint32_t k0, uint32_t k1)
         // v_mul_lo_u32 + v_mul_hi_u32 (each ~4.5 SIMD cycles per wavefront)
         const uint64_t p0 = mul_wide_u32(0xD2511F53u, c.x), p1 = mul_wide_u32(0xCD9E8D57u, c.z);
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        // hi ^ c ^ key as ONE v_bitop3_b32 (gfx950; truth table 0x96 = three-way xor) instead of two v_xor_b32: 16 of a block's 48
+        // instructions.  Round 0 keeps the plain form: its counter words and the key are wave-uniform there and fold into scalars.
+        if (r == 0) c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        else c = u32x4{(uint32_t)__builtin_amdgcn_bitop3_b32(hi1, c.y, k0, 0x96), lo1, (uint32_t)__builtin_amdgcn_bitop3_b32(hi0, c.w, k1, 0x96), lo0};
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -212,13 +215,16 @@ constexpr int kStreamRounds = BN_STREAM_ROUNDS;
 
 // Two independent standard normals from two 32-bit words (Box-Muller).  This is the library's own noise
 // stream, not part of the parity spec, so it uses the hardware transcendentals: v_log_f32, v_sqrt_f32 and
-// v_sin_f32 / v_cos_f32 (which take their argument in revolutions, so 2*pi*u2 is never formed).  ~14
+// v_sin_f32 / v_cos_f32 (which take their argument in revolutions, so 2*pi*u2 is never formed).  ~12
 // instructions per pair instead of ~50 with the precise library forms; bn_mppi_get_philox_noise regenerates
 // the identical values with the same instructions.
+// (round 5) The words enter whole: u1 = fl(a) 2^-32 + 2^-33 in (0, 1] (fl = the conversion's round-to-nearest; the product is
+// exact, so one fma), u2 = fl(b) 2^-32 in [0, 1] revolutions (1 is the angle 0 again).  Round 4 cut both to 24 bits first (a shift
+// each: 4 of a block's 72 instructions); now the small u1 keep all their bits (largest radius 6.76 instead of 5.9).
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
 {
-    const float u1 = (float)(a >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;  // (0,1)
-    const float u2 = (float)(b >> 8) * 5.9604644775390625e-8f;                            // [0,1)
+    const float u1 = __builtin_fmaf((float)a, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float u2 = (float)b * 2.3283064365386963e-10f;
     // -2 ln u1 = (-2 ln 2) * log2(u1)
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
     z0 = rad * __builtin_amdgcn_cosf(u2);
@@ -228,11 +234,16 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &z0, fl
 // The library's own noise stream (BN_NOISE_PHILOX): one Philox block per (instance b, rollout k,
 // step pair p) of solve number `solve`, key = seed.  Pair p holds the (v, omega) noise of steps
 // 2p and 2p+1.
+// FRESH_KEYS: the key words are made opaque at the call, so the round keys (key + r * Weyl constant) are derived by scalar adds at
+// every call instead of living in fourteen scalar registers across the caller's loop -- for a kernel whose loop is short of scalar
+// registers (the one-wave kernel reloaded eight spilled ones per step pair with v_readlane, a vector instruction each).
+template <bool FRESH_KEYS = false>
 __device__ __forceinline__ void philox_eps_pair(uint64_t seed, uint64_t solve, uint32_t b, uint32_t k,
                                                 uint32_t pair, float e[4])
 {
-    const u32x4 r = philox4x32<kStreamRounds>(u32x4{k, pair, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)},
-                                              (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (FRESH_KEYS) asm volatile("" : "+s"(k0), "+s"(k1));
+    const u32x4 r = philox4x32<kStreamRounds>(u32x4{k, pair, (uint32_t)solve ^ (b << 20), (uint32_t)(solve >> 32) ^ (b >> 12)}, k0, k1);
     box_muller(r.x, r.y, e[0], e[1]);   // step 2*pair: (v, omega) noise
     box_muller(r.z, r.w, e[2], e[3]);   // step 2*pair+1
 }

@@ -522,8 +522,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.lean = (cfg->flags & BN_FLAG_LEAN) ? 1 : 0;
     // One-wave kernel, library noise: how much of the horizon the epilogue draws again instead of reading the controls back (see
     // rollout_wave.inc).  Everything with the trajectory dump (its stores already load the memory system), nothing in lean mode.
-    p.regen_steps = p.lean ? 0 : ((p.T + 3) & ~3);
-    if (const char *e = exp_env("BN_REGEN_STEPS")) p.regen_steps = (std::max(0, atoi(e)) + 3) & ~3;      // experiments: tools/regen_split.py
+    p.regen_steps = p.T;
+    p.park_steps = bn::kWaveParkSteps;
+    if (const char *e = exp_env("BN_REGEN_STEPS")) p.regen_steps = std::max(0, atoi(e));      // experiments: tools/wave_ab.py
+    if (const char *e = exp_env("BN_PARK_STEPS")) p.park_steps = std::min(std::max(0, atoi(e)), bn::kWaveParkSteps);
     p.ref_order = ((cfg->flags & BN_FLAG_REFERENCE_ORDER) || big_step) ? 1 : 0;
     // Workgroup i of a launch runs on XCD i % 8 (observed, used for speed only).  xs = 3 interleaves 8 instances along grid x
     // so that the workgroups of one instance share an XCD's L2 (rollout_grid); measured SLOWER (64 instances: 29.2 vs 28.1 us,

@@ -240,7 +240,7 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
         return *(lds_cf *)(uintptr_t)addr;
     }
 #endif
-    if (ASMIDX >= 1) {
+    if (ASMIDX == 1 || ASMIDX == 3) {
         // The latency kernel's chain wave: floor-and-convert in one instruction, row * WN + col as one v_mad_u32_u24 (left to itself
         // the compiler spreads the *4 of the byte address over both terms).  Same integers.  8.65 -> 8.57 us per dependent solve;
         // NOT for the role kernel (64 instances: +3 %): the compiler pads both ends of an asm block with a wait state and cannot
@@ -303,8 +303,8 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
         yn = c.y + (tv * sn) * p.dt;                                   // :87
         tn = c.th + (c.trav * u1) * p.dt;                              // :88
         c.th = wrap_angle(tn);                                         // :90
-        c.x = clampf(xn, p.x0, p.x_hi);                                // :93
-        c.y = clampf(yn, p.y0, p.y_hi);                                // :94
+        c.x = clampf(xn, p.x0, ASMIDX >= 2 ? w.xhi_v : p.x_hi);        // :93
+        c.y = clampf(yn, p.y0, ASMIDX >= 2 ? w.yhi_v : p.y_hi);        // :94
         c.trav = LDSWIN ? trav_window<GEO, ASMIDX>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
         return;
     }
@@ -317,8 +317,8 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     xn = pos.x;
     yn = pos.y;
 #ifdef BN_CHAIN_ASM2
-    c.x = clampf(xn, p.x0, ASMIDX == 2 ? w.xhi_v : p.x_hi);            // :93
-    c.y = clampf(yn, p.y0, ASMIDX == 2 ? w.yhi_v : p.y_hi);            // :94
+    c.x = clampf(xn, p.x0, ASMIDX >= 2 ? w.xhi_v : p.x_hi);            // :93   (ASMIDX 2, 3: the upper limits in vector registers the caller keeps)
+    c.y = clampf(yn, p.y0, ASMIDX >= 2 ? w.yhi_v : p.y_hi);            // :94
 #else
     c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
     c.y = clampf(yn, p.y0, p.y_hi);                                    // :94
@@ -1247,12 +1247,12 @@ __device__ __forceinline__ void produce_pair(const SolveParams &p, const float *
 
 
 // The noise of steps t and t+1 (t even) of rollout kk: the library's Philox stream or the caller's arrays.
-template <int EPS>
+template <int EPS, bool FRESH_KEYS = false>
 __device__ __forceinline__ void noise_pair(const SolveParams &p, int b, int kk, int t, float e[4])
 {
     const int t1 = min(t + 1, p.T - 1);
     if (EPS == kEpsPhilox) {
-        philox_eps_pair(p.seed, p.solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), e);
+        philox_eps_pair<FRESH_KEYS>(p.seed, p.solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), e);
     } else if (EPS == kEpsKT2) {
         const float *row = p.eps + ((size_t)b * p.K + kk) * p.T * 2;
         const float2 v0 = *reinterpret_cast<const float2 *>(row + 2 * t);

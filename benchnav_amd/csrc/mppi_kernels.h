@@ -12,6 +12,7 @@ constexpr int kRolloutThreads = 320;    // 5 wavefronts per workgroup, specialis
 #define BN_CHUNK 4                       // experiments: tools/build_variant.py x -DBN_CHUNK=8 (the latency kernel is left out then)
 #endif
 constexpr int kChunk = BN_CHUNK;                // time steps per barrier phase of the rollout kernel
+constexpr int kWaveParkSteps = 30;       // == kParkSteps of wave_park.h (static_assert in rollout_wave.hip)
 constexpr int kUPad = 65;               // LDS row pitch of the control tile (bank-conflict-free both ways)
 constexpr int kWideFinishThreads = 1024;           // stand-alone tail of the sizes that are not pipelined (K > 2048)
 constexpr int kFinishThreads = kRolloutThreads;   // the tail runs as a stand-alone kernel or as the aux workgroup of a rollout launch
@@ -39,8 +40,10 @@ struct SolveParams {
                          // one instance on one XCD (workgroup i runs on XCD i % 8), 0 is instance-per-row
     int aux_prio;        // the aux workgroups run at wave priority 3: set when the launch exceeds one resident round, so that they
                          // start late (in slots freed by the first rollout workgroups) and must not finish last
-    int regen_steps;     // one-wave kernel, library noise: the epilogue draws the controls of steps [0, regen_steps) again and reads the rest back
-                         // from the control buffer (multiple of 4; T = everything regenerated, 0 = everything round-tripped): VALU against HBM
+    int regen_steps;     // one-wave kernel, library noise: non-zero = the epilogue draws the controls it has not parked again; 0 = they take the
+                         // round trip through the control buffer (what injected noise always does): VALU against HBM traffic
+    int park_steps;      // one-wave kernel: the controls of steps [0, park_steps) wait for their weights in registers of the lane (rollout_wave.inc,
+                         // wave_park.h; at most kWaveParkSteps), 0 = the kernel without the register block
     int lean;            // lean mode: the (K,T+1,3) trajectory batch is not materialised (bn_mppi_reroll regenerates rows on demand)
     int ref_order;       // BN_FLAG_REFERENCE_ORDER (or dt * max|omega| > 0.5): every transit evaluates sincos_spec of its own heading and
                          // updates in the reference's operation order, x + ((trav v) cos) dt (robot_model.py:86-88) -- the oracle's trig = 2.

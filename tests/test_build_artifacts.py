@@ -67,3 +67,75 @@ def test_measured_kernels_have_no_scratch_segment_and_fit_their_occupancy(tmp_pa
     assert max(role.values()) <= 80, role
     wave = {k: v["vgpr"] for k, v in meta.items() if re.search(r"rollout_wave_kernelILi[012]ELi2ELb1E", k)}
     assert max(wave.values()) <= 80, wave
+
+
+def _code_objects(so_path, tmp):
+    fat = os.path.join(tmp, "fat2.bin")
+    subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", so_path, os.devnull])
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+    for i, s in enumerate(starts):
+        blob = os.path.join(tmp, f"b2_{i}.bin")
+        with open(blob, "wb") as f:
+            f.write(data[s:(starts[i + 1] if i + 1 < len(starts) else len(data))])
+        co = os.path.join(tmp, f"co2_{i}.o")
+        r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={blob}", f"--output={co}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], capture_output=True, text=True)
+        if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0:
+            yield co
+
+
+def _park_base():
+    from benchnav_amd import build as b
+    src = open(os.path.join(b.CSRC, "wave_park.h")).read()
+    base = int(re.search(r"#define BN_PARK_BASE (\d+)", src).group(1))
+    steps = int(re.search(r"constexpr int kParkSteps = (\d+);", src).group(1))
+    return base, steps
+
+
+@pytest.mark.skipif(not (os.path.exists(f"{LLVM}/llvm-objdump") and os.path.exists(f"{LLVM}/clang-offload-bundler")), reason="ROCm LLVM tools not installed")
+def test_parked_register_block_is_touched_by_its_two_statements_only(tmp_path):
+    """The one-wave kernel keeps controls in v[BN_PARK_BASE ..] behind the compiler's back (csrc/wave_park.h).  In the SHIPPED code
+    objects: every rollout_wave_park_kernel allocates exactly 128 registers and has no VGPR spill, and no instruction outside an
+    s_set_gpr_idx_on ... s_set_gpr_idx_off bracket names a register of the block; inside a bracket only v_mov_b32 to / from the
+    block's first four registers appears (the hardware adds the index)."""
+    from benchnav_amd import _capi
+    from benchnav_amd import build as b
+    _capi.load()
+    base, steps = _park_base()
+    assert base + 2 * steps == 128
+    meta = _kernel_metadata(b.LIB_PATH, str(tmp_path))
+    park = {k: v for k, v in meta.items() if "rollout_wave_park_kernel" in k}
+    assert len(park) >= 36, sorted(park)
+    assert all(v["vgpr"] == 128 and v["vgpr_spills"] == 0 for v in park.values()), park
+    seen, brackets = 0, 0
+    for co in _code_objects(b.LIB_PATH, str(tmp_path)):
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+        cur, inside = None, False
+        for line in dis.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1) if "rollout_wave_park_kernel" in m.group(1) else None
+                seen += cur is not None
+                inside = False
+                continue
+            if cur is None:
+                continue
+            t = line.split("//")[0].strip()
+            if not t:
+                continue
+            if t.startswith("s_set_gpr_idx_on"):
+                assert not inside, (cur, t)
+                inside, brackets = True, brackets + 1
+                continue
+            if t.startswith("s_set_gpr_idx_off"):
+                assert inside, (cur, t)
+                inside = False
+                continue
+            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", t)] + [int(hi) for _, hi in re.findall(r"\bv\[(\d+):(\d+)\]", t)]
+            if inside:
+                assert t.startswith("v_mov_b32"), (cur, t)
+                assert sum(base <= r < base + 4 for r in regs) == 1 and all(r < base + 4 for r in regs), (cur, t)
+            else:
+                assert all(r < base for r in regs), f"{cur}: `{t}` touches the parked block (v{base}..)"
+    assert seen == len(park) and brackets >= 2 * seen, (seen, brackets)
