@@ -95,6 +95,7 @@ SYMBOLS = {
     "bn_mppi_row_pitch": (C.c_int32, [_H]),
     "bn_mppi_kernel_ms": (C.c_int, [_H, _FP, _FP, C.POINTER(C.c_int32)]),
     "bn_mppi_algorithmic_bytes": (C.c_int64, [_H, C.c_int]),
+    "bn_mppi_algorithmic_bytes_window": (C.c_int64, [_H, C.c_int]),
     "bn_risk_map_infer": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_float,
                                     C.c_int32, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_int]),
     "bn_risk_last_error": (C.c_char_p, []),

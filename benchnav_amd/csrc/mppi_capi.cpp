@@ -142,7 +142,8 @@ struct bn_mppi {
     // writes solve i-1's tail (U*, X*, weights).  `tail_pending` = the latest solve's tail has not been
     // written yet; flush() launches the finish kernel for it.
     bool pipelined = false;
-    bool slow_path = false;          // rollout_wave_kernel + stand-alone tail, two launches per solve: BN_FLAG_REFERENCE_ORDER, dt |omega| > 0.5, horizons beyond the role kernels' LDS
+    bool slow_path = false;          // rollout_wave_kernel + stand-alone tail, two launches per solve: horizons beyond the role kernels' LDS, or the reference-order
+                                     // arithmetic together with sampled slip (the reference order by itself runs on every kernel family, one launch per solve)
     bool tail_pending = false;
     // device buffers
     float *d_map = nullptr, *d_state = nullptr, *d_goal = nullptr, *d_mean = nullptr, *d_eps = nullptr;
@@ -273,6 +274,8 @@ int ensure_scratch(bn_mppi *h, size_t bytes)
     return BN_OK;
 }
 
+int guard_foreign_overlap(bn_mppi *h);      // (defined with order_behind_foreign_overlap)
+
 // Write the tail (U*, next mean, X*, weights, cost copy) of the latest solve if it is still pending.
 int flush_tail(bn_mppi *h, float *out_copy = nullptr)
 {
@@ -294,6 +297,7 @@ int flush_tail(bn_mppi *h, float *out_copy = nullptr)
     p.flag_tail = h->d_flags + kSlots * (size_t)p.B * bn::kFlagStride;        // every tail counts itself in (stream-ordered here: nothing to wait for)
     h->tails += 1;
     if (h->overlap_used) p.err_dev = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * (size_t)p.B + 2) * bn::kFlagStride);   // behind overlapped launches: see raise_wait_expired
+    if (int rc = guard_foreign_overlap(h)) return rc;
     BN_HIP(bn::launch_finish(p, h->stream));
     h->tail_pending = false;
     return BN_OK;
@@ -649,8 +653,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     if (const char *e = exp_env("BN_LAT_KERNEL")) h->lat_kernel = h->lat_kernel && e[0] != '0';      // experiments
     alloc(&h->d_flags, ((kSlots + 1) * B + 3) * bn::kFlagStride * sizeof(unsigned long long));      // [kSlots][B] + [B] counters, a spare slot, the device error word
     alloc(&h->d_mean_snap, B * T * 2 * 4);
-    h->snap_cap = std::max<size_t>(64, std::min<size_t>(4096, ((size_t)16 << 20) / ((size_t)B * 12)));      // at most 16 MB of them (B <= 341: the journal's own 4096)
-    alloc(&h->d_state_snaps, h->snap_cap * B * 3 * 4);
+    // (the journal's state snapshots, d_state_snaps, are allocated below, and only for a handle that can overlap at all)
     if (rc == BN_OK) {
         if (hipHostMalloc((void **)&h->h_err, 64, hipHostMallocMapped) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostMalloc (error word) failed");
         else if (hipHostGetDevicePointer((void **)&h->d_err, h->h_err, 0) != hipSuccess) rc = fail(BN_ERR_HIP, "hipHostGetDevicePointer failed");
@@ -683,6 +686,10 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
             if (h->d_X) alloc(&h->d_Xalt[q], B * (T + 1) * 3 * (size_t)p.Kp * 4);
             if (h->d_U) alloc(&h->d_Ualt[q], B * T * 2 * (size_t)p.Kp * 4);
         }
+        // the journal's state snapshots: only a handle that can overlap ever journals (up to 16 MB per handle otherwise,
+        // times the planners of a K-sharded or per-instance set-up).  At most 16 MB; B <= 341 get the journal's own 4096 entries.
+        h->snap_cap = std::max<size_t>(64, std::min<size_t>(4096, ((size_t)16 << 20) / ((size_t)B * 12)));
+        alloc(&h->d_state_snaps, h->snap_cap * B * 3 * 4);
     }
     if (rc == BN_OK && may_overlap) {
         bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -760,7 +767,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
                 h->parked.push_back(h->xstream[q]);        // kept alive until destroy: destroying it would hand its queue slot to the next one
                 h->xstream[q] = fresh;
             }
-            if (std::getenv("BN_DEBUG_CREATE")) std::fprintf(stderr, "[bn_mppi_create] extra stream %d: %s after %zu replacement(s)\n", q, found ? "dispatches concurrently" : "NO concurrent queue found", h->parked.size());
+            if (exp_env("BN_DEBUG_CREATE")) std::fprintf(stderr, "[bn_mppi_create] extra stream %d: %s after %zu replacement(s)\n", q, found ? "dispatches concurrently" : "NO concurrent queue found", h->parked.size());
             // No stream that dispatches concurrently with the handle's: launches of a batch would not overlap, and workgroups waiting
             // on the device for a predecessor the queue has not started yet would only burn their bounded waits.  One stream then.
             if (!found && rc == BN_OK) h->overlap_off = true;
@@ -937,6 +944,16 @@ static int order_behind_foreign_overlap(bn_mppi *h, hipStream_t st)
     return BN_OK;
 }
 
+// Every launch a handle makes on its own stream outside an overlapped batch of its own -- stand-alone tails, re-rolls, environment
+// steps and collision checks, not only solves -- goes behind another handle's overlapped batch the same way.
+namespace {
+int guard_foreign_overlap(bn_mppi *h)
+{
+    if (h->last_batch_overlapped || g_overlap_owners.load(std::memory_order_relaxed) == 0) return BN_OK;
+    return order_behind_foreign_overlap(h, h->stream);
+}
+}  // namespace
+
 // shard_rollout: the rollouts of a K-sharded solve only (bn_mppi_shard_rollout_async); the tail follows the exchange.
 static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise,
                       bool shard_rollout, bool overlap = false, hipStream_t on_stream = nullptr, int alt_buffers = 0, bool self_tail = false)
@@ -954,6 +971,10 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     bn::SolveParams p = h->p;
     const size_t B = p.B, K = p.K, T = p.T;
     h->map_epoch_at_solve = h->map_epoch;
+    // Behind an overlapped batch the host has not checked yet (or batches journalled for a re-run): a plain launch's tail must not
+    // write the mean from partials of an expired wait either (flush_tail does the same) -- see raise_wait_expired
+    if (h->d_flags && (h->overlap_used || !h->journal.empty()))
+        p.err_dev = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 2) * bn::kFlagStride);
     if (states_where == BN_MEM_DEVICE) {
         p.state = states;
     } else {
@@ -1453,6 +1474,7 @@ int bn_mppi_env_step(bn_mppi_t *h, const float *actions_device, float *states_de
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_step");
     BN_BIND(h);
     if (int rc = settle_point(h)) return rc;
+    if (int rc = guard_foreign_overlap(h)) return rc;
     BN_HIP(bn::launch_env_step(h->p, actions_device, states_device, rewards_device, terminated_device, z_device, step_index, h->stream));
     return BN_OK;
 }
@@ -1465,6 +1487,7 @@ int bn_mppi_env_collision_check(bn_mppi_t *h, const float *states_device, int32_
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_env_collision_check");
     BN_BIND(h);
     if (int rc = settle_point(h)) return rc;
+    if (int rc = guard_foreign_overlap(h)) return rc;
     BN_HIP(bn::launch_env_collision(h->p, states_device, n_positions, stuck_threshold, z_device, draw_index, out_device, h->stream));
     return BN_OK;
 }
@@ -1474,8 +1497,8 @@ int bn_mppi_episode_async(bn_mppi_t *h, int32_t n_steps, const float *states0, b
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!h->env_attached) return fail(BN_ERR_STATE, "bn_mppi_env_attach must precede bn_mppi_episode_async");
-    if (h->slow_path) return fail(BN_ERR_INVALID, "the fused device-side closed loop is not available on the slow path (BN_FLAG_REFERENCE_ORDER, dt * |omega| > 0.5, "
-                                                   "or a horizon beyond the role kernels' LDS): drive bn_mppi_forward_async + bn_mppi_env_step instead");
+    if (h->slow_path) return fail(BN_ERR_INVALID, "the fused device-side closed loop is not available on the slow path (a horizon beyond the role kernels' LDS, or the "
+                                                   "reference-order arithmetic together with sampled slip): drive bn_mppi_forward_async + bn_mppi_env_step instead");
     if (!h->pipelined) return fail(BN_ERR_INVALID, "the device-side closed loop needs the pipelined mode (num_samples <= 4096)");
     if (n_steps < 1) return fail(BN_ERR_INVALID, "n_steps must be >= 1");
     BN_BIND(h);
@@ -1739,6 +1762,7 @@ static int reroll_rows(bn_mppi_t *h, int32_t instance, const int *idx_device, in
     p.solve = h->solves - 1;
     p.state = h->d_state_copy[cur];
     p.eps = h->last_eps;
+    if (int rc = guard_foreign_overlap(h)) return rc;
     BN_HIP(bn::launch_reroll(p, h->last_mode, instance, idx_device, n, out_device, h->stream));
     return BN_OK;
 }
@@ -1962,6 +1986,17 @@ int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise)
     if (noise != BN_NOISE_PHILOX) bytes += 8 * K * T;   // injected noise read
     if (h->p.store_u) bytes += 8 * K * T;               // _perturbed_action_seqs write
     return bytes;
+}
+
+/* The same with the map term replaced by what a solve can reach: the LDS window of (WN x WN) cells around the start state, staged
+ * once per instance in the best case (every rollout workgroup stages its own copy; the copies hit in L2).  With BN_FLAG_LEAN the
+ * map read is most of SURVEY 8d's lean formula, and a kernel that reads the window only would be credited for bytes it never
+ * moves: bench.py reports both fractions. */
+int64_t bn_mppi_algorithmic_bytes_window(const bn_mppi_t *h, bn_noise_kind noise)
+{
+    if (!h) return 0;
+    const int64_t G = h->p.G, W = h->p.WN > 0 ? h->p.WN : G;
+    return bn_mppi_algorithmic_bytes(h, noise) - 4 * G * G + 4 * W * W;
 }
 
 #ifdef BN_TIMING

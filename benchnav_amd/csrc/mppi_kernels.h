@@ -47,7 +47,7 @@ struct SolveParams {
     int lean;            // lean mode: the (K,T+1,3) trajectory batch is not materialised (bn_mppi_reroll regenerates rows on demand)
     int ref_order;       // BN_FLAG_REFERENCE_ORDER (or dt * max|omega| > 0.5): every transit evaluates sincos_spec of its own heading and
                          // updates in the reference's operation order, x + ((trav v) cos) dt (robot_model.py:86-88) -- the oracle's trig = 2.
-                         // Served by the one-wave kernel + stand-alone tail, two launches per solve (chain_step<..., REF = true>)
+                         // Every kernel family has an instantiation in this arithmetic (rollout_role_ref_*.hip, rollout_wave_ref.hip; chain_step<..., REF = true>)
     float res, inv_res;
     float x0, y0;        // index origin == lower clamp (reference grid_map.py:199-201, robot_model.py:93-94)
     float x_hi, y_hi;    // upper clamp

@@ -99,7 +99,8 @@ class MPPI(nn.Module):
                       winners on demand and `_state_seq_batch` re-rolls all K rows when it is read, bit-identical either way.
       reference_order the transit in the reference's own operation order (robot_model.py:86-88: sin / cos of every step's
                       heading, x + ((trav v) cos) dt): no cell flips against the reference beyond what libm vs SLEEF gives
-                      (DESIGN.md 5), at ~4x the latency (two launches per solve).  The default arithmetic leaves about one
+                      (DESIGN.md 5), on the same kernels (one launch per solve) at ~1.4x the single-instance latency -- the chain's extra
+                      instructions; 1-8 % for batched launches.  The default arithmetic leaves about one
                       rollout in 30 000 (T = 50) in a neighbouring cell.  `arithmetic` tells which one a planner runs; a
                       `delta_t * max|omega|` above 0.5 rad selects the reference order by itself.
 

@@ -313,6 +313,8 @@ class NativeMPPI:
         _capi.check(self._lib.bn_mppi_kernel_ms(self._h, C.byref(r), C.byref(f), C.byref(n)))
         return r.value, f.value, n.value
 
-    def algorithmic_bytes(self, injected_noise: bool = True) -> int:
+    def algorithmic_bytes(self, injected_noise: bool = True, window: bool = False) -> int:
+        """SURVEY 8d's algorithmic bytes of one solve; window=True counts the reachable LDS window instead of the whole map."""
         kind = _capi.BN_NOISE_DEVICE_KT2 if injected_noise else _capi.BN_NOISE_PHILOX
-        return int(self._lib.bn_mppi_algorithmic_bytes(self._h, kind))
+        fn = self._lib.bn_mppi_algorithmic_bytes_window if window else self._lib.bn_mppi_algorithmic_bytes
+        return int(fn(self._h, kind))

@@ -92,8 +92,8 @@ enum {
                                           T = 100) then lands in a neighbouring cell and leaves the 1e-4 trajectory tolerance from there on
                                           (tests/golden/census_*.npz); with this flag none did in 0.7 M rollouts at T = 50 and
                                           one in 0.7 M at T = 100 -- the level of libm against the reference's own SLEEF.  Every kernel has
-                                          an instantiation in this arithmetic; the price is the chain's extra instructions: 12.5 instead of
-                                          8.7 us per dependent single-instance solve, 1-8 % for batched launches and K > 4096 (DESIGN.md
+                                          an instantiation in this arithmetic; the price is the chain's extra instructions: 11.7 instead of
+                                          8.5 us per dependent single-instance solve, 1-8 % for batched launches and K > 4096 (DESIGN.md
                                           4.15).  dt * max|omega| > 0.5 selects this arithmetic
                                           by itself).  bn_mppi_arithmetic() tells which arithmetic a handle runs. */
 };
@@ -213,7 +213,17 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
  * its state tensor in place between batches got the re-run on the new contents).
  * The call returns BN_OK with a warning in bn_last_error(), bn_mppi_recovery_count() counts these events (consumers enqueued in
  * stream order BEFORE the synchronisation point have read invalid buffers), and the handle keeps to one stream from then on.
- * BN_ERR_HIP only when the batches cannot be re-run (host-resident inputs; more than min(4096, 16 MB / (12 B x num_instances), at least 64) batches without a synchronising call). */
+ * BN_ERR_HIP only when the batches cannot be re-run (host-resident inputs; more than min(4096, 16 MB / (12 B x num_instances), at least 64) batches without a synchronising call).
+ * Host side of the call.  "async" means the call does not wait for the solves -- but it is not free of host waits: a batch whose
+ * launches exceed one residency round each (64+ instances of K = 1024 on the role kernel) hands its first three launches over one
+ * by one -- the host spins on a pinned word (a few microseconds; at most 2 ms per hand-over, then it falls back to
+ * hipStreamSynchronize on that launch's stream, which also waits for whatever the caller queued there before) --, and a batch of
+ * such launches that finds the handle's stream busy synchronises it first.  Small launches (the single-instance path) never block.
+ * Threads.  A handle is not thread-safe, and the handles of ONE device are not independent of each other while overlapped batches
+ * are in use: the library orders every launch of a handle behind another handle's overlapped batch that may still be in flight
+ * (solves, stand-alone tails, re-rolls, environment steps), and it decides that from host-side state it reads at the call.  Calls
+ * that concern one device must therefore come from one thread at a time (the caller's lock, or one thread per device); handles on
+ * different devices are independent.  BN_FLAG_NO_OVERLAP on every handle of a device lifts the restriction for those handles. */
 int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_kind states_where,
                           const float *eps, bn_noise_kind noise, int32_t eps_ring, int64_t eps_stride);
 
@@ -370,6 +380,10 @@ int bn_mppi_kernel_ms(bn_mppi_t *h, float *rollout_ms, float *finish_ms, int32_t
 
 /* Algorithmic HBM bytes of one solve in the current mode (DESIGN.md "Roofline"). */
 int64_t bn_mppi_algorithmic_bytes(const bn_mppi_t *h, bn_noise_kind noise);
+/* ... with the map term (4 G^2) replaced by the reachable window the kernels stage (4 WN^2): the bytes a solve has to move when
+ * only a corner of the map can be reached within the horizon.  The roofline fraction of a lean launch against THIS figure is the
+ * honest one (SURVEY 8d's lean formula counts the whole map). */
+int64_t bn_mppi_algorithmic_bytes_window(const bn_mppi_t *h, bn_noise_kind noise);
 
 /*
  * TraversabilityModel._infer_risk_map, traversability_model.py:28-51 (runs once per dynamics object, in
