@@ -461,6 +461,100 @@ def run_episode_case():
           f"(terminated {ep_term[-1]}) -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+RISK_SCALE_C2 = 0.75     # as episodes.npz: some cells below the stuck threshold
+
+
+def run_episode_c2_case():
+    """ONE free-running closed-loop episode of the reference at BASELINE configs[1] size (K=1024, T=50, 256x256 map)
+    with the REAL MPPI and the REAL PlanetaryEnv (test_mppi.py:171-198, planetary_env.py:189-219), stored for a like-for-like
+    free-running replay.  The noise blocks (K*T*2 floats per solve) are not stored: the generator state in front of every
+    solver.forward() is (5056 bytes), and any host regenerates block i as set_rng_state(state_i); empty(K,T,2).normal_() -- checked
+    here against solver._action_noises bit for bit.  The slip draw of every env.step is stored as its standard normal, and the U* of
+    every solve (the next solve's mean) for a teacher-forced check beside the free-running one.
+    A free-running replay at this size is CHAOTIC, and the fixture demonstrates it with the reference itself: lambda = 0.5 against
+    cost spreads of several units puts 20-100 % of a solve's weight on ONE rollout (ep_wmax), so which rollout wins decides the
+    control.  The same episode is therefore run eight more times from start states one or two ULPS away (x, y, heading), on the
+    identical random stream (generator state restored in front of every forward): ulp_steps, ulp_spread (and the first run's
+    states, ep_states_ulp).  What the reference's nine runs agree on -- the range of arrival steps, the deviation they reach -- is
+    what a free-running replay on another implementation can be held to; step-by-step agreement is checked teacher-forced (state
+    and previous U* of the reference in front of every solve).
+    """
+    from src.simulator.planetary_env import PlanetaryEnv
+    import matplotlib.pyplot as plt
+    G, res, thr, K, T, seed = 256, 0.5, 0.3, 1024, 50, 7
+    mean_map = smooth_risk_map(G, 33) * RISK_SCALE_C2
+    std_map = slip_std_map(G, 33)
+    start, goal = torch.tensor([40.0, 38.0]), torch.tensor([43.5, 41.0])
+    gm = _env_grid_map(G, res, mean_map, std_map)
+    env = PlanetaryEnv(grid_map=gm, start_pos=start, goal_pos=goal, seed=seed, delta_t=0.1, time_limit=40.0, stuck_threshold=thr, device="cpu")
+    dyn = UnicycleModel(grid_map=gm, model_config=ModelConfig(mode="inference", inference_metric="expected_value"), device="cpu")
+    obj = Objectives(dyn, goal_pos=env._goal_pos, stuck_threshold=env.stuck_threshold)
+    solver = MPPI(horizon=T, num_samples=K, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, sigmas=torch.tensor([0.5, 0.5]),
+                  lambda_=0.5, device=torch.device("cpu"), seed=seed)
+    with _CaptureNormal() as cap:
+        state = env.reset(seed=seed)
+        plt.close("all")
+        cap.take()
+        ep_states, ep_rng, ep_z, ep_act, ep_term, ep_ustar, ep_wmax = [state.numpy().copy()], [], [], [], [], [], []
+        for i in range(400):
+            rng = torch.get_rng_state().clone()
+            with torch.no_grad():
+                action_seq, state_seq = solver.forward(state=state)
+            after = torch.get_rng_state()
+            torch.set_rng_state(rng)
+            assert torch.equal(torch.empty(K, T, 2).normal_() * torch.tensor([0.5, 0.5]), solver._action_noises), "noise regeneration drifted"
+            assert torch.equal(torch.get_rng_state(), after)
+            ep_rng.append(rng.numpy().copy()); ep_ustar.append(action_seq.numpy().copy()); ep_wmax.append(float(solver._weights.max()))
+            state, reward, is_term, is_trunc = env.step(action_seq[0, :])
+            (z,) = cap.take()
+            env.collision_check(states=state_seq)
+            cap.take()
+            ep_states.append(state.numpy().copy()); ep_z.append(float(z)); ep_act.append(action_seq[0].numpy().copy()); ep_term.append(bool(is_term))
+            if is_term or is_trunc:
+                break
+    assert ep_term[-1], "the stored episode must arrive"
+    # the same episode from starts one or two ulps away, on the same random stream (block i % n beyond the stored episode's length, as a
+    # replay with a noise ring does): the reference's own sensitivity -- arrival steps and largest deviation of eight such runs
+    def perturbed(coord, ulps):
+        env2 = PlanetaryEnv(grid_map=gm, start_pos=start, goal_pos=goal, seed=seed, delta_t=0.1, time_limit=40.0, stuck_threshold=thr, device="cpu")
+        solver2 = MPPI(horizon=T, num_samples=K, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, sigmas=torch.tensor([0.5, 0.5]),
+                       lambda_=0.5, device=torch.device("cpu"), seed=seed)
+        st = env2.reset(seed=seed).clone()
+        plt.close("all")
+        for _ in range(abs(ulps)):
+            st[coord] = torch.nextafter(st[coord], torch.tensor(float("inf") if ulps > 0 else -float("inf")))
+        env2._robot_state = st.clone()
+        sts, term = [st.numpy().copy()], []
+        for i in range(400):
+            torch.set_rng_state(torch.from_numpy(ep_rng[i % len(ep_rng)]))
+            with torch.no_grad():
+                action_seq, state_seq = solver2.forward(state=st)
+            st, reward, is_term, is_trunc = env2.step(action_seq[0, :])
+            env2.collision_check(states=state_seq)
+            sts.append(st.numpy().copy()); term.append(bool(is_term))
+            if is_term or is_trunc:
+                break
+        m = min(len(sts), len(ep_states))
+        return sts, term, float(np.abs(np.asarray(sts[:m]) - np.asarray(ep_states[:m])).max())
+    runs = [perturbed(c, u) for c, u in ((0, 1), (0, -1), (1, 1), (1, -1), (2, 1), (2, -1), (0, 2), (1, 2))]
+    ulp_states, ulp_term, ulp_dev = runs[0]
+    ulp_steps = [len(r[1]) for r in runs]
+    ulp_spread = [r[2] for r in runs]
+    assert all(r[1][-1] for r in runs), "every perturbed run must arrive"
+    R = dyn._traversability_model._risks.clone()
+    out = dict(G=G, res=res, thr=thr, K=K, T=T, seed=seed, R=R.numpy(), MU=mean_map.numpy(), SG=std_map.numpy(), start=start.numpy(), goal=goal.numpy(),
+               goal_threshold=1.0, delta_t=0.1, ep_states=np.asarray(ep_states, np.float32), ep_rng=np.asarray(ep_rng, np.uint8),
+               ep_z=np.asarray(ep_z, np.float32), ep_actions=np.asarray(ep_act, np.float32), ep_terminated=np.asarray(ep_term),
+               ep_ustar=np.asarray(ep_ustar, np.float32), ep_wmax=np.asarray(ep_wmax, np.float32),
+               ep_states_ulp=np.asarray(ulp_states, np.float32), ep_terminated_ulp=np.asarray(ulp_term),
+               ulp_steps=np.asarray(ulp_steps, np.int32), ulp_spread=np.asarray(ulp_spread, np.float32), torch_version=torch.__version__)
+    path = os.path.join(HERE, "episode_c2.npz")
+    np.savez_compressed(path, **out)
+    print(f"episode_c2     K={K} T={T} G={G}: {len(ep_z)} control steps (terminated {ep_term[-1]}), largest weight median {np.median(ep_wmax):.3f} "
+          f"max {max(ep_wmax):.3f}; started 1-2 ulp away the reference arrives after {ulp_steps} steps, "
+          f"states up to {max(ulp_spread):.3f} apart -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def run_instance_io_case():
     """N4: a map-instance file written by benchnav_amd.io.save_instance (the layout of dataset_generator.py:302-305) is read by
     the REFERENCE's own loading path (test_mppi.py:42-44 -> GridMap, grid_map.py:100-143) and what the reference's objects hold
@@ -803,10 +897,13 @@ def main():
         return run_env_case()
     if sys.argv[1:] == ["episodes"]:
         return run_episode_case()
+    if sys.argv[1:] == ["episode_c2"]:
+        return run_episode_c2_case()
     run_census()
     run_boundary_case()
     run_env_case()
     run_episode_case()
+    run_episode_c2_case()
     run_instance_io_case()
     run_riskmap_case()
     run_sampled_case()

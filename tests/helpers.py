@@ -14,6 +14,29 @@ def load_case(name):
     return {k: z[k] for k in z.files}
 
 
+def regenerate_noise_blocks(fx):
+    """Fixtures that store the torch CPU generator's state in front of every solve instead of the noise itself (episode_c2.npz:
+    5 KB instead of 410 KB per solve): block i = set_rng_state(ep_rng[i]); empty(K,T,2).normal_() -- what the reference's
+    MultivariateNormal.rsample draws (mppi.py:149-151; checked bit for bit against solver._action_noises at capture).  The global
+    generator is left as it was found."""
+    import torch
+    K, T = int(fx["K"]), int(fx["T"])
+    keep = torch.get_rng_state()
+    out = np.empty((len(fx["ep_rng"]), K, T, 2), np.float32)
+    for i, st in enumerate(fx["ep_rng"]):
+        torch.set_rng_state(torch.from_numpy(np.ascontiguousarray(st)))
+        out[i] = torch.empty(K, T, 2).normal_().numpy()
+    torch.set_rng_state(keep)
+    return out
+
+
+def episode_c2_bounds(fx):
+    """(first, last admissible arrival step count, largest admissible deviation): what the reference's own nine runs -- the stored
+    episode and eight from starts 1-2 ulps away on the same random stream -- span, with a margin of two steps / a factor of two."""
+    steps = np.concatenate([fx["ulp_steps"], [len(fx["ep_terminated"])]])
+    return int(steps.min()) - 2, int(steps.max()) + 2, 2.0 * float(fx["ulp_spread"].max())
+
+
 def oracle_params_for(fx, trig):
     from oracle import oracle as O
     return O.make_params(int(fx["K"]), int(fx["T"]), int(fx["G"]), float(fx["res"]), fx["goal"],

@@ -58,3 +58,42 @@ def test_replayed_reference_episode_free_running():
     assert np.abs(actions[:, 0] - fx["ep_actions"]).max() <= 2e-2
     first = int(np.argmax(fx["ep_terminated"]))
     assert fx["ep_terminated"][first] and done[0] == first            # arrives at the very same control step
+
+
+@pytest.mark.parametrize("reference_order", [False, True])
+def test_reference_episode_at_baseline_size(reference_order):
+    """the closed loop at BASELINE configs[1] size (K=1024, T=50, 256x256 map) against 75 control steps of the REAL
+    MPPI + PlanetaryEnv (tests/golden/episode_c2.npz; the noise blocks are regenerated from stored generator states), in both
+    arithmetics.  (1) teacher-forced through the C ABI -- the reference's state and previous U* in front of every solve: every U*
+    within SURVEY 8a (iv).  (2) free-running on the device (bn_mppi_episode_async, the reference's noise blocks and slip draws): a
+    closed loop that puts most of a solve's weight on one rollout is chaotic, the fixture holds the reference's own run from a
+    starts one or two ulps away, and the device is held to what those runs span: their range of arrival steps (+-2) and twice their
+    largest deviation (tests/test_episodes_golden.py has the oracle's side of the same check)."""
+    import torch
+    from benchnav_amd import NativeMPPI, _capi
+    from helpers import episode_c2_bounds, regenerate_noise_blocks
+    fx = load_case("episode_c2")
+    eps_h = regenerate_noise_blocks(fx)
+    K, T, G, n = int(fx["K"]), int(fx["T"]), int(fx["G"]), len(fx["ep_z"])
+    common = dict(horizon=T, num_samples=K, grid_size=G, resolution=float(fx["res"]), stuck_threshold=float(fx["thr"]), reference_order=reference_order)
+    with NativeMPPI(**common) as pl:
+        assert pl.arithmetic() == ("reference_order" if reference_order else "spec")
+        pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
+        worst = 0.0
+        for i in range(n):
+            pl.set_mean(fx["ep_ustar"][i - 1] if i else None)
+            us, xs = pl.solve(fx["ep_states"][i], eps_h[i])
+            worst = max(worst, float(np.abs(us[0] - fx["ep_ustar"][i]).max()))
+        assert worst <= 2e-3, worst                                    # SURVEY 8a (iv): 2e-2; the oracle reaches 6e-5
+    lo, hi, dev_max = episode_c2_bounds(fx)
+    eps = torch.from_numpy(eps_h).cuda()
+    z = torch.from_numpy(np.resize(fx["ep_z"], hi)).cuda()           # (beyond the stored episode draws and blocks repeat, as in the fixture's perturbed runs)
+    with NativeMPPI(**common) as pl:
+        pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
+        pl.env_attach(fx["MU"], fx["SG"], goal_threshold=float(fx["goal_threshold"]), delta_t=float(fx["delta_t"]))
+        states, rewards, done = pl.episode(hi, fx["ep_states"][0], z_device_ptr=z.data_ptr(), eps_ptr=eps.data_ptr(),
+                                           kind=_capi.BN_NOISE_DEVICE_KT2, eps_ring=n, eps_stride=K * T * 2)
+    assert done[0] >= 0 and lo <= int(done[0]) + 1 <= hi, (done[0], lo, hi)
+    m = min(int(done[0]) + 2, len(fx["ep_states"]))
+    dev = np.abs(states[:m, 0] - fx["ep_states"][:m]).max()
+    assert dev <= dev_max, (dev, dev_max)
