@@ -82,9 +82,40 @@ def reference_costs(solver, obj, mean):
     return torch.sum(stage, dim=1) + term + torch.sum(solver._lambda * act, dim=1)
 
 
+def reference_order_spread(solver, dyn, obj, mean, state):
+    """what the REFERENCE's own weights / U* / X* do when its per-step cost terms (its own fp32 stage_cost and control
+    cost values, bit for bit) are summed in another order -- steps reversed, strictly left to right, in fp64 -- than torch.sum's
+    vectorised one (mppi.py:186-190).  Every variant is the reference's arithmetic up to the order of T + 1 additions; how far they
+    lie from the stored result is the reference's own conditioning on this case.  Returns {name: (w, U*, X*)}."""
+    X, U = solver._state_seq_batch, solver._perturbed_action_seqs
+    K, T, lam = solver._num_samples, solver._horizon, solver._lambda
+    stage, act = torch.zeros(K, T), torch.zeros(K, T)
+    for t in range(T):
+        stage[:, t] = obj.stage_cost(X[:, t, :], U[:, t, :])
+        act[:, t] = mean[t] @ solver._inv_covariance @ U[:, t].T
+    term = obj.terminal_cost(X[:, -1, :])
+    seq_s, seq_a = torch.zeros(K), torch.zeros(K)
+    for t in range(T):
+        seq_s = seq_s + stage[:, t]
+        seq_a = seq_a + lam * act[:, t]
+    costs = {"reversed": torch.sum(stage.flip(1), dim=1) + term + torch.sum((lam * act).flip(1), dim=1),
+             "sequential": seq_s + term + seq_a,
+             "fp64": (stage.double().sum(1) + term.double() + (lam * act).double().sum(1)).float()}
+    out = {}
+    for name, c in costs.items():
+        w = torch.softmax(-c / lam, dim=0)
+        ustar = torch.sum(w.view(K, 1, 1) * U, dim=0)
+        xs = torch.zeros(1, T + 1, 3)
+        xs[:, 0, :] = state
+        for t in range(T):                               # mppi.py:202-214, the reference's own transit (with its aliasing)
+            xs[:, t + 1, :] = dyn.transit(xs[:, t, :], ustar.repeat(1, 1, 1)[:, t, :])
+        out[name] = (w.numpy().copy(), ustar.numpy().copy(), xs[0].numpy().copy())
+    return out
+
+
 def run_case(name, *, G, res, K, T, risk_mean, risk_std=None, metric="expected_value",
              confidence=0.9, start, goal, thr=0.3, sigmas=(0.5, 0.5), lam=0.5, seed=42,
-             n_solves=1, x_stride=1, advance="fixed"):
+             n_solves=1, x_stride=1, advance="fixed", order_spread=False):
     torch.manual_seed(1234)          # _infer_risk_map (var/cvar) consumes the global stream
     std_map = risk_std if risk_std is not None else torch.full((G, G), 0.1)
     gm, dyn, obj = build_reference(G, res, risk_mean, std_map, metric, confidence, goal, thr)
@@ -119,6 +150,9 @@ def run_case(name, *, G, res, K, T, risk_mean, risk_std=None, metric="expected_v
         out[f"Xstar_{i}"] = X_opt[0].numpy().copy()
         out[f"w_{i}"] = solver._weights.numpy().copy()
         out[f"cost_{i}"] = cost.numpy().copy()
+        if order_spread:
+            for nm, (w_a, u_a, x_a) in reference_order_spread(solver, dyn, obj, mean, state_in).items():
+                out[f"w_{nm}_{i}"], out[f"Ustar_{nm}_{i}"], out[f"Xstar_{nm}_{i}"] = w_a, u_a, x_a
         out[f"U_{i}"] = solver._perturbed_action_seqs[::x_stride].numpy().copy()
         out[f"X_{i}"] = solver._state_seq_batch[::x_stride].numpy().copy()
         if advance == "follow":      # crude closed loop: jump to the 5th predicted (clamped) state
@@ -897,6 +931,9 @@ def main():
         return run_env_case()
     if sys.argv[1:] == ["episodes"]:
         return run_episode_case()
+    if sys.argv[1:] == ["c2_stuck"]:
+        return run_case("c2_stuck", G=256, res=0.5, K=1024, T=50, risk_mean=smooth_risk_map(256, 0),
+                        start=[32.0, 32.0, pi / 4], goal=torch.tensor([96.0, 96.0]), n_solves=1, x_stride=8, order_spread=True)
     if sys.argv[1:] == ["episode_c2"]:
         return run_episode_c2_case()
     run_census()
@@ -945,7 +982,7 @@ def main():
     # same sizes, start inside a stuck region: every rollout collides at every step, costs ~5.1e5,
     # the weights are decided by the last fp32 ulp of the cost (ill-conditioned in the reference itself)
     run_case("c2_stuck", G=256, res=0.5, K=1024, T=50, risk_mean=smooth_risk_map(256, 0),
-             start=[32.0, 32.0, pi / 4], goal=torch.tensor([96.0, 96.0]), n_solves=1, x_stride=8)
+             start=[32.0, 32.0, pi / 4], goal=torch.tensor([96.0, 96.0]), n_solves=1, x_stride=8, order_spread=True)
 
 
 if __name__ == "__main__":

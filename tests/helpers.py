@@ -77,12 +77,35 @@ TOL_REF = dict(U_max=0.0, X_max=1e-4, cost_outlier_frac=5e-3, cost_outlier_resid
                w_max=5e-3, Ustar_max=2e-2, Ustar_rms=2e-3, Xstar_max=1e-3)
 
 
-# c2_stuck starts inside a stuck region: all 1024 rollouts collide at every step, every cost is
-# ~5.1e5 where one fp32 ulp is 0.03-0.06, and lambda = 0.5 turns one ulp into a 6-13 % change of a
-# weight.  The reference's own result depends on its summation order there, so the weights and U*
-# get the looser bound (the trajectories and the per-rollout costs keep the tight one).
+# c2_stuck starts inside a stuck region: all 1024 rollouts collide at every step, every cost is ~5.1e5 where one fp32 ulp is
+# 0.03-0.06, and lambda = 0.5 turns one ulp into a 6-13 % change of a weight: the reference's own result depends on the order in
+# which it adds its T + 1 cost terms.  That is not asserted here, it is in the fixture: make_golden.py stores the
+# reference's weights / U* / X* with ITS OWN per-step cost values summed in three other orders (steps reversed, left to right,
+# fp64; `reference_order_spread`).  An implementation is held to SURVEY 8a (iii)/(iv) or to 1.5 x the largest distance between the
+# reference and those variants of itself, whichever is larger -- per metric, per solve; the trajectories and the per-rollout costs
+# keep the tight bound.
 ILL_CONDITIONED = {"c2_stuck"}
-TOL_REF_ILL = dict(TOL_REF, w_max=2e-2, Ustar_max=3e-2, Ustar_rms=1.5e-2, Xstar_max=3e-3)
+ORDER_VARIANTS = ("reversed", "sequential", "fp64")
+
+
+def reference_order_spread(fx, i):
+    """Largest distance between the reference's stored result of solve i and its own summation-order variants, per metric."""
+    sp = dict(w_max=0.0, Ustar_max=0.0, Ustar_rms=0.0, Xstar_max=0.0)
+    for nm in ORDER_VARIANTS:
+        du = fx[f"Ustar_{nm}_{i}"] - fx[f"Ustar_{i}"]
+        sp["w_max"] = max(sp["w_max"], float(np.abs(fx[f"w_{nm}_{i}"] - fx[f"w_{i}"]).max()))
+        sp["Ustar_max"] = max(sp["Ustar_max"], float(np.abs(du).max()))
+        sp["Ustar_rms"] = max(sp["Ustar_rms"], float(np.sqrt(np.mean(du ** 2))))
+        sp["Xstar_max"] = max(sp["Xstar_max"], float(np.abs(fx[f"Xstar_{nm}_{i}"] - fx[f"Xstar_{i}"]).max()))
+    return sp
+
+
+def tolerance_for(name, fx, i):
+    """TOL_REF, widened for the ill-conditioned cases to 1.5 x the reference's own summation-order spread on that solve."""
+    if name not in ILL_CONDITIONED:
+        return TOL_REF
+    return dict(TOL_REF, **{k: max(TOL_REF[k], 1.5 * v) for k, v in reference_order_spread(fx, i).items()})
+
 
 # HIP kernels against the oracle in spec-trig mode: integer-like exactness where the arithmetic
 # spec fixes every rounding (controls, trajectories, per-rollout costs), tight tolerance where the

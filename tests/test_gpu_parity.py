@@ -9,8 +9,8 @@ Tiers (DESIGN.md "Parity tiers"):
 import numpy as np
 import pytest
 
-from helpers import (CASES, ILL_CONDITIONED, TOL_REF, TOL_REF_ILL, assert_oracle_parity, assert_within, load_case,
-                     native_outputs, native_planner_for, oracle_metrics, oracle_params_for, parity_metrics)
+from helpers import (CASES, ILL_CONDITIONED, TOL_REF, assert_oracle_parity, assert_within, load_case,
+                     native_outputs, native_planner_for, oracle_metrics, oracle_params_for, parity_metrics, tolerance_for)
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,6 @@ def test_fixture_cases_teacher_forced(name, lds_window):
     O = _oracle()
     fx = load_case(name)
     p = oracle_params_for(fx, O.TRIG_SPEC)
-    tol = TOL_REF_ILL if name in ILL_CONDITIONED else TOL_REF
     with native_planner_for(fx, lds_window=lds_window) as pl:
         pl.set_map(fx["R"]); pl.set_goal(fx["goal"])
         for i in range(int(fx["n_solves"])):
@@ -35,7 +34,7 @@ def test_fixture_cases_teacher_forced(name, lds_window):
             got = native_outputs(pl, us, xs)
             orc = O.solve(p, fx["R"], fx[f"state_{i}"], fx[f"mean_{i}"], fx[f"eps_{i}"])
             assert_oracle_parity(oracle_metrics(got, orc), ctx=f"{name} solve {i}")
-            assert_within(parity_metrics(got, fx, i), tol, ctx=f"{name} solve {i}")
+            assert_within(parity_metrics(got, fx, i), tolerance_for(name, fx, i), ctx=f"{name} solve {i}")
             assert np.array_equal(pl.get_mean(), us[0]), "warm start must be U* unshifted (mppi.py:217)"
 
 
