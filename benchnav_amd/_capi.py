@@ -65,6 +65,9 @@ SYMBOLS = {
     "bn_mppi_shard_rollout_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_shard_partials": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bn_mppi_shard_finish_async": (C.c_int, [_H, C.c_void_p, C.c_int32]),
+    "bn_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "bn_mppi_shard_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
+    "bn_mppi_shard_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_env_attach": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint64]),
     "bn_mppi_env_set_freeze": (C.c_int, [_H, C.c_int32]),
     "bn_mppi_env_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),

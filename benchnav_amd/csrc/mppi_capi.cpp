@@ -19,6 +19,8 @@
 #include <fcntl.h>
 #include <sys/file.h>
 #include <unistd.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library itself is opened at run time (rccl_api), and only by a K-sharded solve
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -204,6 +206,16 @@ struct bn_mppi {
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
+    void *shard_comm = nullptr;      // ncclComm_t of bn_mppi_shard_comm_init: the exchange is enqueued by the library on the handle's stream
+    int shard_world = 0, shard_rank = 0;
+    bool shard_inplace = false;               // set around the rollouts of bn_mppi_shard_solve_async
+    float *d_gathered = nullptr;     // (shard_world x nblk, 2 + 2T): every shard's partial rows, rank order
+    float *d_shard_merged = nullptr; // kSlots x [U* (2T) then (max z, sum e)]: what the merge kernel hands to the tail on the side stream
+    hipStream_t shard_side = nullptr;         // the tail of a library-enqueued sharded solve runs here, beside the next solve's rollouts
+    bool shard_side_own = false;
+    hipEvent_t ev_shard_merge = nullptr, ev_shard_tail[kSlots] = {};      // tail events by solve slot (see bn_mppi_shard_solve_async)
+    int shard_tail_slot = 0;                  // slot of the latest tail
+    bool shard_tail_inflight = false;         // the handle's stream has not been ordered behind the latest side-stream tail yet
     bool ticket_mode = false;        // one launch per solve: ticket merge by the last workgroup + the previous tail as aux
                                      // workgroup (sampled-slip kernel; deterministic kernel at K > 2048)
     bool slip_std_set = false;
@@ -279,6 +291,10 @@ int guard_foreign_overlap(bn_mppi *h);      // (defined with order_behind_foreig
 // Write the tail (U*, next mean, X*, weights, cost copy) of the latest solve if it is still pending.
 int flush_tail(bn_mppi *h, float *out_copy = nullptr)
 {
+    if (h->shard_tail_inflight) {                      // K-sharded solve, library-enqueued: results are ordered on the handle's stream from here on
+        BN_HIP(hipStreamWaitEvent(h->stream, h->ev_shard_tail[h->shard_tail_slot], 0));
+        h->shard_tail_inflight = false;
+    }
     if (!h->tail_pending) return BN_OK;
     bn::SolveParams p = h->p;
     p.out_copy = out_copy;
@@ -786,6 +802,8 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     return BN_OK;
 }
 
+static void shard_comm_release(bn_mppi *h);      // (with the RCCL loader, further down)
+
 void bn_mppi_destroy(bn_mppi_t *h)
 {
     if (!h) return;
@@ -800,6 +818,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
         v.erase(std::remove(v.begin(), v.end(), h), v.end());
     }
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->shard_comm) shard_comm_release(h);
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost_out,
                     h->d_w, h->d_ustar /* d_xstar lives in the same block */, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
@@ -1147,6 +1166,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         h->tail_pending = true;
         return BN_OK;
     }
+    // library-enqueued exchange of a K-sharded solve: the shard's rows go straight to their place among the gathered ones (in-place all-gather)
+    if (shard_rollout && h->shard_inplace) p.part = h->d_gathered + (size_t)h->shard_rank * p.nblk * (2 + 2 * T);
     if (p.slip_on) {
         BN_HIP(bn::launch_rollout_sampled(p, mode, h->stream));
     } else {
@@ -1245,6 +1266,159 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
     p.nblk = total_workgroups;
     p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
     BN_HIP(bn::launch_finish(p, h->stream));                 // weights of the local rollouts, normalised by the global sum
+    h->shard_pending = false;
+    return BN_OK;
+}
+
+// ---- the exchange of a K-sharded solve enqueued by the library: RCCL on the handle's stream -----------------------------------
+// Round 4's ShardedMPPI drove the three steps from Python -- launch, torch.distributed.all_gather_into_tensor (its own stream, two
+// events to fence it against the planner's), launch: 60 us per solve on one rank against 28 unsharded.  Here the triple is ONE C call
+// and ONE queue: rollout kernel, ncclAllGather, tail kernel, stream-ordered, no host wait, no event.  RCCL is opened with dlopen on
+// first use: the library has no link-time dependency on it, and a process that never shards a solve never loads it.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+const RcclApi *rccl_api()
+{
+    static const RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.all_gather = reinterpret_cast<decltype(a.all_gather)>(dlsym(a.lib, "ncclAllGather"));
+        a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(a.lib, "ncclGetErrorString"));
+        if (!a.get_unique_id || !a.comm_init_rank || !a.all_gather || !a.comm_destroy || !a.error_string) a.lib = nullptr;
+        return a;
+    }();
+    return api.lib ? &api : nullptr;
+}
+}  // namespace
+
+static void shard_comm_release(bn_mppi *h)
+{
+    if (h->shard_side) (void)hipStreamSynchronize(h->shard_side);
+    if (const RcclApi *r = rccl_api()) (void)r->comm_destroy(static_cast<ncclComm_t>(h->shard_comm));
+    h->shard_comm = nullptr;
+    if (h->d_gathered) (void)hipFree(h->d_gathered);
+    if (h->d_shard_merged) (void)hipFree(h->d_shard_merged);
+    h->d_gathered = h->d_shard_merged = nullptr;
+    if (h->ev_shard_merge) (void)hipEventDestroy(h->ev_shard_merge);
+    for (hipEvent_t &e : h->ev_shard_tail) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    h->ev_shard_merge = nullptr;
+    if (h->shard_side_own && h->shard_side) (void)hipStreamDestroy(h->shard_side);
+    h->shard_side = nullptr;
+}
+
+int bn_dist_unique_id(uint8_t out[BN_DIST_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == BN_DIST_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!out) return fail(BN_ERR_INVALID, "null output");
+    const RcclApi *r = rccl_api();
+    if (!r) return fail(BN_ERR_HIP, "librccl.so could not be opened: %s", dlerror());
+    ncclUniqueId id;
+    const ncclResult_t e = r->get_unique_id(&id);
+    if (e != ncclSuccess) return fail(BN_ERR_HIP, "ncclGetUniqueId: %s", r->error_string(e));
+    std::memcpy(out, &id, sizeof(id));
+    return BN_OK;
+}
+
+int bn_mppi_shard_comm_init(bn_mppi_t *h, const uint8_t unique_id[BN_DIST_UNIQUE_ID_BYTES], int32_t world_size, int32_t rank)
+{
+    if (!h || !unique_id) return fail(BN_ERR_INVALID, "null argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(BN_ERR_INVALID, "rank %d outside a world of %d", rank, world_size);
+    if (h->p.B != 1 || h->p.slip_on) return fail(BN_ERR_INVALID, "a K-sharded solve takes one instance per handle, without sampled slip");
+    if (h->shard_comm) return fail(BN_ERR_STATE, "the handle has a communicator already");
+    const RcclApi *r = rccl_api();
+    if (!r) return fail(BN_ERR_HIP, "librccl.so could not be opened: %s", dlerror());
+    BN_BIND(h);
+    if (int rc = settle_point(h)) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t e = r->comm_init_rank(&comm, world_size, id, rank);      // collective: every rank of the solve calls it
+    if (e != ncclSuccess) return fail(BN_ERR_HIP, "ncclCommInitRank: %s", r->error_string(e));
+    const size_t bytes = (size_t)world_size * h->p.nblk * (2 + 2 * (size_t)h->p.T) * sizeof(float);
+    if (hipMalloc((void **)&h->d_gathered, bytes) != hipSuccess) {
+        (void)r->comm_destroy(comm);
+        return fail(BN_ERR_HIP, "hipMalloc of %zu B for the gathered partials failed", bytes);
+    }
+    h->shard_comm = comm;
+    h->shard_world = world_size;
+    h->shard_rank = rank;
+    // the side stream of the tail: the handle's second stream if it has one (overlapped batches), else one of its own
+    // [ kSlots merged rows | 64 group rows | ticket ]
+    const size_t merged_floats = kSlots * (2 * (size_t)h->p.T + 2) + 64 * (2 + 2 * (size_t)h->p.T) + 4;
+    if ((size_t)world_size * h->p.nblk > 1024) { shard_comm_release(h); return fail(BN_ERR_INVALID, "the library's exchange merges at most 1024 workgroups (65536 rollouts)"); }
+    bool ok = hipMalloc((void **)&h->d_shard_merged, merged_floats * sizeof(float)) == hipSuccess &&
+              hipMemset(h->d_shard_merged, 0, merged_floats * sizeof(float)) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_shard_merge, hipEventDisableTiming) == hipSuccess;
+    for (int q = 0; ok && q < kSlots; ++q) ok = hipEventCreateWithFlags(&h->ev_shard_tail[q], hipEventDisableTiming) == hipSuccess;
+    if (ok && h->n_streams > 1 && h->xstream[0]) h->shard_side = h->xstream[0];
+    else if (ok) { ok = hipStreamCreateWithFlags(&h->shard_side, hipStreamNonBlocking) == hipSuccess; h->shard_side_own = ok; }
+    if (!ok) { shard_comm_release(h); return fail(BN_ERR_HIP, "stream / event / buffer creation for the sharded solve failed"); }
+    return BN_OK;
+}
+
+int bn_mppi_shard_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!h->shard_comm) return fail(BN_ERR_STATE, "bn_mppi_shard_comm_init must precede bn_mppi_shard_solve_async");
+    // The rollouts of THIS solve do not wait for the previous solve's tail on the side stream (flush_tail would join it): they read
+    // the mean the merge wrote, on this stream.  And they write their partial rows where the all-gather wants them (in place).
+    const bool inflight = h->shard_tail_inflight;
+    h->shard_tail_inflight = false;
+    h->shard_inplace = true;
+    const int rc0 = bn_mppi_shard_rollout_async(h, states, states_where, eps, noise);
+    h->shard_inplace = false;
+    h->shard_tail_inflight = inflight;
+    if (rc0) return rc0;
+    BN_BIND(h);
+    const int cur = (int)((h->solves - 1) % kSlots);
+    const size_t count = (size_t)h->p.nblk * (2 + 2 * (size_t)h->p.T);          // equal shards: every rank contributes the same rows
+    const RcclApi *r = rccl_api();
+    const ncclResult_t e = r->all_gather(h->d_gathered + (size_t)h->shard_rank * count, h->d_gathered, count, ncclFloat,
+                                         static_cast<ncclComm_t>(h->shard_comm), h->stream);
+    if (e != ncclSuccess) return fail(BN_ERR_HIP, "ncclAllGather: %s", r->error_string(e));
+    // Merge on the handle's stream -- U*, the next mean, the softmin statistics: all the next solve's rollouts wait for -- and the
+    // rest of the tail (X* rollout, the shard's weights, the cost copy: ~10 us of one workgroup) on the side stream, beside them.
+    // What the two streams share: the outputs (tails stay in order on their one stream), the per-solve slots of costs / states, and
+    // the merged row (written by the merge, read by the tail) -- all rotating over kSlots solves.  A merge reuses the slot of the tail
+    // four solves back: that tail is done unless something is badly stuck, so the host LOOKS (hipEventQuery) and only a tail still
+    // running puts a cross-queue wait in front of the merge -- an event wait between queues costs microseconds on the handle's
+    // stream even when the event has long fired (first cut of this path: 72 us per solve with the wait against 47 without the split).
+    if (int rc = settle_point(h)) return rc;
+    bn::SolveParams p = h->p;
+    p.solve = p.tail_solve = h->solves - 1;
+    p.part = h->d_gathered;                                  // merged in shard order: identical on every rank
+    p.nblk = h->shard_world * h->p.nblk;
+    p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
+    float *merged = h->d_shard_merged + (size_t)cur * (2 * (size_t)p.T + 2);
+    p.ustar_cur = merged; p.stats_cur = merged + 2 * (size_t)p.T;
+    if (h->solves > (uint64_t)kSlots && hipEventQuery(h->ev_shard_tail[cur]) != hipSuccess) {
+        (void)hipGetLastError();
+        BN_HIP(hipStreamWaitEvent(h->stream, h->ev_shard_tail[cur], 0));
+    }
+    float *group_rows = h->d_shard_merged + kSlots * (2 * (size_t)p.T + 2);
+    BN_HIP(bn::launch_shard_merge(p, group_rows, reinterpret_cast<int *>(group_rows + 64 * (2 + 2 * (size_t)p.T)), h->stream));
+    BN_HIP(hipEventRecord(h->ev_shard_merge, h->stream));
+    BN_HIP(hipStreamWaitEvent(h->shard_side, h->ev_shard_merge, 0));
+    p.tail_merged = 1;
+    p.ustar_prev = merged; p.stats_prev = merged + 2 * (size_t)p.T;
+    BN_HIP(bn::launch_finish(p, h->shard_side));            // weights of the local rollouts, normalised by the global sum; X*
+    BN_HIP(hipEventRecord(h->ev_shard_tail[cur], h->shard_side));
+    h->shard_tail_slot = cur;
+    h->shard_tail_inflight = true;
     h->shard_pending = false;
     return BN_OK;
 }
@@ -1905,6 +2079,10 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
 int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size_t *bytes)
 {
     if (!h || !device_ptr) return fail(BN_ERR_INVALID, "null argument");
+    if (h->shard_tail_inflight) {                     // a library-enqueued sharded solve: order the handle's stream behind its tail first
+        BN_BIND(h);
+        if (int rc = flush_tail(h)) return rc;
+    }
     void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost_out, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal, h->d_ustar};
     if ((int)id < 0 || id >= BN_BUF_COUNT_) return fail(BN_ERR_INVALID, "unknown buffer id %d", (int)id);
     *device_ptr = ptrs[id];

@@ -157,6 +157,8 @@ int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
+// K-sharded solve: merge of all shards' partial rows -> ustar_cur, stats_cur, ustar, mean.  group_rows: 64 x (2 + 2T) floats, ticket: one zeroed int
+hipError_t launch_shard_merge(const SolveParams &p, float *group_rows, int *ticket, hipStream_t s);
 // rows idx[0..n) (nullptr: 0..n) of instance b's trajectory batch of the solve described by p (p.solve, p.eps, p.state, p.mean_used)
 hipError_t launch_reroll(const SolveParams &p, EpsMode mode, int b, const int *idx, int n, float *out_n_T1_3, hipStream_t s);
 hipError_t launch_rollout_sampled(const SolveParams &p, EpsMode mode, hipStream_t s);

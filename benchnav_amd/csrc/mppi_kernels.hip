@@ -38,6 +38,47 @@ __global__ __launch_bounds__(NT) void finish_kernel(const SolveParams p)
 }
 
 // ------------------------------------------------------------------------------
+// K-sharded solve: the merge of ALL shards' partial rows on its own -- U* (= the next mean) and the softmin statistics, which is
+// all the NEXT solve's rollouts wait for.  The rest of the tail (X*, the shard's weights, the cost copy) follows as
+// finish_kernel with p.tail_merged on a second stream, beside the next solve's rollouts (bn_mppi_shard_solve_async).
+// The arithmetic is the stand-alone tail's (merge_group per 16 rows, then merge_partials over the group rows; plain merge_partials
+// up to 64 rows): the same bits whoever runs it.  More than 64 rows: one workgroup PER GROUP, its four waves splitting the
+// columns, so that every row is in flight at once (one workgroup walking 16 groups x 4 column blocks took 7.7 us of a 42 us solve at
+// 256 rows); the last group to finish (ticket) merges the group rows.  grid = groups (or 1), block = 256.
+// LDS: [ us 2T | scale 64 | red 32 | flag ].
+// ------------------------------------------------------------------------------
+constexpr int kShardMergeThreads = 256;
+__global__ __launch_bounds__(kShardMergeThreads) void shard_merge_kernel(const SolveParams p, float *grows, int *ticket)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = p.T, tid = threadIdx.x, PS = 2 + 2 * p.T;
+    float *us = smem, *sc = us + 2 * T, *red = sc + 64;
+    int *flag = reinterpret_cast<int *>(red + 32);
+    float m, S;
+    if (p.nblk > 64) {
+        const int g = blockIdx.x, ng = gridDim.x;
+        merge_group<false, true>(p.part, g * kGroupRows, min(kGroupRows, p.nblk - g * kGroupRows), T, tid & 63, tid >> 6, kShardMergeThreads / 64,
+                                 grows + (size_t)g * PS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *flag = (atomicAdd(ticket, 1) == ng - 1) ? 1 : 0;
+        __syncthreads();
+        if (!*flag) return;
+        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next solve (stream-ordered)
+        merge_partials<kShardMergeThreads, true, false>(grows, ng, T, us, sc, red, tid, m, S, false, MergeLoads{});
+    } else {
+        merge_partials<kShardMergeThreads, false, false>(p.part, p.nblk, T, us, sc, red, tid, m, S, false, MergeLoads{});
+    }
+    for (int j = tid; j < 2 * T; j += kShardMergeThreads) {
+        p.ustar_cur[j] = us[j];
+        p.ustar[j] = us[j];                             // (the tail writes the same values again: U* is on the handle's stream from here on)
+        if (p.mean_used) p.mean_used[j] = p.mean[j];    // what this solve sampled around
+        p.mean[j] = us[j];                              // _previous_action_seq = U*, no shift (mppi.py:217)
+    }
+    if (tid == 0) { p.stats_cur[0] = m; p.stats_cur[1] = S; }
+}
+
+// ------------------------------------------------------------------------------
 // Re-roll: rows of _state_seq_batch (mppi.py:119-125, 160-165) of the LATEST solve regenerated on demand -- the same noise
 // (Philox stream position or the caller's eps), the mean that solve sampled around (mean_used), the state it started from,
 // the same device functions in the same order as the rollout kernels: bit-identical to what a full-API solve stored.
@@ -443,6 +484,17 @@ hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)
     case kEpsKT2: return launch_rollout_role_kt2(p, s);
     default: return launch_rollout_role_t2k(p, s);
     }
+}
+
+hipError_t launch_shard_merge(const SolveParams &p, float *group_rows, int *ticket, hipStream_t s)
+{
+    if (p.nblk > 64 * kGroupRows) return hipErrorInvalidValue;       // (K > 65536: not sharded through the library's exchange)
+    const size_t lds = sizeof(float) * (2 * (size_t)p.T + 64 + 32 + 4);
+    const unsigned ng = p.nblk > 64 ? (unsigned)((p.nblk + kGroupRows - 1) / kGroupRows) : 1u;
+    hipError_t e = ensure_lds(shard_merge_kernel, lds);
+    if (e != hipSuccess) return e;
+    shard_merge_kernel<<<dim3(ng), dim3(kShardMergeThreads), lds, s>>>(p, group_rows, ticket);
+    return hipGetLastError();
 }
 
 hipError_t launch_finish(const SolveParams &p, hipStream_t s)

@@ -165,6 +165,15 @@ class NativeMPPI:
         _capi.check(self._lib.bn_mppi_shard_rollout_async(self._h, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
                                                           C.c_void_p(eps_ptr), kind))
 
+    def shard_comm_init(self, unique_id: bytes, world_size: int, rank: int):
+        """Collective: the ranks of a K-sharded solve build the RCCL communicator the library enqueues its exchange on."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _capi.check(self._lib.bn_mppi_shard_comm_init(self._h, C.cast(buf, C.c_void_p), world_size, rank))
+
+    def shard_solve_async_device(self, state_ptr: int, eps_ptr: Optional[int] = None, kind: int = _capi.BN_NOISE_PHILOX):
+        """Rollouts of the shard, all-gather of the partial rows (RCCL on the handle's stream), merge + tail: one call, one queue."""
+        _capi.check(self._lib.bn_mppi_shard_solve_async(self._h, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE, C.c_void_p(eps_ptr), kind))
+
     def shard_partials(self):
         """(device pointer, workgroups, floats per workgroup) of the shard's softmin partials."""
         ptr, n, ps = C.c_void_p(), C.c_int32(), C.c_int32()

@@ -8,6 +8,7 @@ instances (BASELINE.json config 4).  The only exchange is the final gather of pe
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -79,6 +80,15 @@ def shard_rollouts(num_samples: int, world_size: int, rank: int):
     return 64 * groups[0], 64 * len(groups)
 
 
+def unique_id() -> bytes:
+    """128 bytes of ncclGetUniqueId, drawn by the library (bn_dist_unique_id): what rank 0 hands to the ranks of a K-sharded solve."""
+    import ctypes as C
+    from . import _capi
+    buf = (C.c_uint8 * 128)()
+    _capi.check(_capi.load().bn_dist_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
+
+
 def merge_partials_reference(partials):
     """NumPy statement of the exchange step: merge per-workgroup (max z, sum e, sum e*u[2T]) rows, in row order,
     into (max z, sum e, U* (T,2)).  What bn_mppi_shard_finish_async computes on the device; used by the CPU tests."""
@@ -126,6 +136,15 @@ class ShardedMPPI:
             self._send = torch.zeros(maxc, PS, dtype=torch.float32, device=where)
             self._recv = torch.empty(self.world * maxc, PS, dtype=torch.float32, device=where)
         self._views = {}                                 # partial rows of the planner's per-solve slots, wrapped once each
+        # Equal shards on RCCL: the library enqueues the exchange itself -- rollout kernel, ncclAllGather, tail kernel on the planner's
+        # one stream, one C call per solve (bn_mppi_shard_solve_async; round 4 drove three calls and torch's collective stream from
+        # here: 60 us per solve on one rank).  The communicator's id travels over the group the job has anyway.
+        self._fused = False
+        if self._direct and self._dist is not None and os.environ.get("BN_SHARD_TORCH_COLLECTIVE") != "1":
+            box = [unique_id() if self.rank == 0 else None]
+            self._dist.broadcast_object_list(box, src=self._dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            self.planner.shard_comm_init(box[0], self.world, self.rank)
+            self._fused = True
 
     def _view(self, ptr, shape):
         from .mppi import _DevArray
@@ -142,6 +161,12 @@ class ShardedMPPI:
         """state_dev: (3,) float32 on the GPU; eps_dev: this rank's slice of the noise or None (Philox in-kernel).
         Three stream-ordered steps, nothing allocated: rollouts of the shard, all-gather of the partial rows, merge + tail."""
         from . import _capi
+        if self._fused:
+            if eps_dev is None:
+                self.planner.shard_solve_async_device(state_dev.data_ptr())
+            else:
+                self.planner.shard_solve_async_device(state_dev.data_ptr(), eps_dev.data_ptr(), _capi.BN_NOISE_DEVICE_KT2 if kind is None else kind)
+            return self
         if eps_dev is None:
             self.planner.shard_rollout_async_device(state_dev.data_ptr())
         else:
@@ -166,6 +191,7 @@ class ShardedMPPI:
     def results(self):
         """(U* (T,2), X* (T+1,3)) of the latest solve as device tensors (views of planner memory, stream-ordered)."""
         from . import _capi
+        self.planner.flush()                             # (library-enqueued exchange: joins the side-stream tail; enqueue only)
         us = self._view(self.planner.device_buffer(_capi.BN_BUF_USTAR)[0], (self.T, 2))
         xs = self._view(self.planner.device_buffer(_capi.BN_BUF_XSTAR)[0], (self.T + 1, 3))
         return us, xs

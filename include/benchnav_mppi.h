@@ -240,6 +240,23 @@ int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout);
 int bn_mppi_shard_rollout_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise);
 int bn_mppi_shard_partials(bn_mppi_t *h, const float **partials_device, int32_t *workgroups, int32_t *floats_per_workgroup);
 int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, int32_t total_workgroups);
+/* The same three steps as ONE call with the exchange enqueued by the library: RCCL's ncclAllGather on the handle's own stream
+ * between the two kernels -- no host wait, no event, no second stream (what a caller driving steps 1-3 through
+ * torch.distributed pays per solve).  Equal shards only (num_samples the same on every rank).  RCCL is opened with dlopen
+ * on first use; nothing else in the library depends on it.
+ *   bn_dist_unique_id          rank 0 draws the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any means
+ *                              (benchnav_amd.sharding broadcasts them over the torch.distributed group the job has anyway)
+ *   bn_mppi_shard_comm_init    collective over the ranks of the solve (ncclCommInitRank on the handle's device); the communicator
+ *                              and the buffer of gathered partial rows belong to the handle and go with bn_mppi_destroy
+ *   bn_mppi_shard_solve_async  rollouts of the shard, all-gather of the partial rows (rank order), merge + tail
+ * Results are those of steps 1-3 above: bit-identical on every rank and to the unsharded solve.  Ordering: U* and the next mean are
+ * written on the handle's stream by the merge; X*, the shard's weights and the cost copy by a tail the library runs on a second
+ * stream beside the NEXT solve's rollouts -- they are ordered on the handle's stream by the next call that concerns results
+ * (bn_mppi_flush, bn_mppi_sync, any getter, bn_mppi_device_buffer), which enqueues the join without blocking the host. */
+#define BN_DIST_UNIQUE_ID_BYTES 128
+int bn_dist_unique_id(uint8_t out[BN_DIST_UNIQUE_ID_BYTES]);
+int bn_mppi_shard_comm_init(bn_mppi_t *h, const uint8_t unique_id[BN_DIST_UNIQUE_ID_BYTES], int32_t world_size, int32_t rank);
+int bn_mppi_shard_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise);
 /*
  * Device-side closed loop: PlanetaryEnv.step (planetary_env.py:189-219) between consecutive solves, for
  * all B instances, without a host round trip per control step (the reference loop: test_mppi.py:171-198).

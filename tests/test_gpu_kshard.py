@@ -151,6 +151,7 @@ inst = synth.make_instance(G, seed=4)
 st = inst.start.cuda()
 sh = ShardedMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=77)
 assert sh._dist is not None and not sh._host_backend and sh.world == 1
+assert sh._fused == (os.environ.get("BN_SHARD_TORCH_COLLECTIVE") != "1"), sh._fused
 sh.planner.set_map(inst.risk.numpy()); sh.planner.set_goal(inst.goal.numpy())
 outs = []
 for i in range(3):                                   # warm-started chain: every solve's exchange goes through all_gather_into_tensor
@@ -169,15 +170,20 @@ print("RCCL-ONE-RANK-OK", dist.is_nccl_available())
 """
 
 
-def test_sharded_solve_over_an_rccl_group_of_one():
-    """ShardedMPPI with torch.distributed initialised on backend "nccl" (= RCCL) and a world of one: the exchange runs through
-    all_gather_into_tensor on device memory -- the branch an 8-GPU job takes -- and the chain of three warm-started solves is
-    bit-identical to the unsharded planner's.  In a subprocess: the process group must not leak into the test session."""
+@pytest.mark.parametrize("exchange", ["library", "torch"])
+def test_sharded_solve_over_an_rccl_group_of_one(exchange):
+    """ShardedMPPI with torch.distributed initialised on backend "nccl" (= RCCL) and a world of one -- the branch an 8-GPU job
+    takes.  `library`: the exchange is enqueued by the library itself (bn_mppi_shard_solve_async: rollout kernel, ncclAllGather on
+    the planner's stream through a communicator of its own, tail kernel; the id travels over the torch group); `torch`: round 4's
+    three calls with all_gather_into_tensor (BN_SHARD_TORCH_COLLECTIVE=1, what ragged shards still take).  Either way the chain of
+    three warm-started solves is bit-identical to the unsharded planner's.  In a subprocess: the process group must not leak."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BN_SHARD_TORCH_COLLECTIVE")}
+    if exchange == "torch":
+        env["BN_SHARD_TORCH_COLLECTIVE"] = "1"
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611" if exchange == "torch" else "29613", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
