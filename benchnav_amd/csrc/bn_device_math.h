@@ -38,14 +38,9 @@ __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
     // two plain FMAs, pinned: left to itself the vectoriser packs them into one v_pk_fma_f32 whose operand pairs cost two
     // register moves and a hazard slot -- four issue slots instead of two on the one wave whose slots are the solve's latency
     float S, C;
-#ifdef BN_VAR_NO_SINCOS_ASM
-    S = __builtin_fmaf(pq.x * s, r, r);
-    C = __builtin_fmaf(pq.y, s, 1.0f);
-#else
     const float ps = pq.x * s;
     asm("v_fma_f32 %0, %1, %2, %2" : "=v"(S) : "v"(ps), "v"(r));
     asm("v_fma_f32 %0, %1, %2, 1.0" : "=v"(C) : "v"(pq.y), "v"(s));
-#endif
     const uint32_t sign = __float_as_uint(t) << 31;          // parity of n
     sn = __uint_as_float(__float_as_uint(S) ^ sign);
     cs = __uint_as_float(__float_as_uint(C) ^ sign);
@@ -65,7 +60,6 @@ __device__ __forceinline__ void sincos_spec(float x, float &sn, float &cs)
 template <bool ONEBLOCK = false>
 __device__ __forceinline__ void rotate_spec(float &cs, float &sn, float d, v2f c0_pinned = v2f{0.0f, 0.0f})
 {
-#ifdef BN_CHAIN_ASM2
     if (ONEBLOCK) {
         // The latency kernel's chain wave: the seven instructions below as the compiler emits them for the statements that
         // follow, in ONE asm block -- between the packed multiply (op_sel_hi[0] = 1) and the asm of the last FMA the hazard
@@ -86,7 +80,6 @@ __device__ __forceinline__ void rotate_spec(float &cs, float &sn, float d, v2f c
         sn = h.y;
         return;
     }
-#endif
     const float d2 = d * d;
     const v2f dd = {d2, d2};
     v2f pq = __builtin_elementwise_fma(dd, v2f{-0.00138888892251998186f, -0.000198412701138295233f}, v2f{0.0416666679084300995f, 0.00833333376795053482f});
@@ -98,11 +91,7 @@ __device__ __forceinline__ void rotate_spec(float &cs, float &sn, float d, v2f c
     // (cs, sn) * cd + (-(sn*sd), cs*sd): the swap and the (exact) negation of the addend ride on the packed FMA's operand
     // selectors -- spelled out, the compiler forms (-sn, cs) with a v_xor and a v_mov first, two more issue slots per step
     v2f r;
-#ifdef BN_VAR_NO_ROTATE_ASM
-    r = __builtin_elementwise_fma(h, v2f{pq.x, pq.x}, v2f{-u.y, u.x});
-#else
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,0] neg_lo:[0,0,1]" : "=v"(r) : "v"(h), "v"(pq), "v"(u));
-#endif
     cs = r.x;
     sn = r.y;
 }
@@ -208,10 +197,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 // variant a 20-byte scratch segment -- the emergency slot tests/test_build_artifacts.py exists to catch: 23 -> 28 us per
 // 64-instance launch.)  The library's own stream is not part of the parity spec;
 // bn_mppi_get_philox_noise / bn_mppi_get_slip_noise regenerate exactly what the kernels consume.
-#ifndef BN_STREAM_ROUNDS
-#define BN_STREAM_ROUNDS 8
-#endif
-constexpr int kStreamRounds = BN_STREAM_ROUNDS;
+constexpr int kStreamRounds = 8;
 
 // Two independent standard normals from two 32-bit words (Box-Muller).  This is the library's own noise
 // stream, not part of the parity spec, so it uses the hardware transcendentals: v_log_f32, v_sqrt_f32 and

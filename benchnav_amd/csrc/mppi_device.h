@@ -3,15 +3,6 @@
 // Everything here has internal linkage (anonymous namespace); each .hip file instantiates what it launches.
 #pragma once
 #include "mppi_kernels.h"
-// Round 4's cut of the latency kernel's chain wave and producers (on; -DBN_VAR_R3_CHAIN builds the previous one for A/B runs,
-// tools/variant_ab.py): BN_CHAIN_ASM2 -- the gather's address arithmetic and the rotation as one asm block each (no hazard
-// wait states around them), BN_RING_IMM -- ring slots and control rows through one address register per chunk and immediate
-// offsets, BN_PREDRAW -- the horizon's Philox noise drawn into the control tile while the predecessor's rows are still on their way.
-#ifndef BN_VAR_R3_CHAIN
-#define BN_CHAIN_ASM2 1
-#define BN_RING_IMM 1
-#define BN_PREDRAW 1
-#endif
 #include "bn_device_math.h"
 
 #include <math.h>
@@ -24,56 +15,20 @@ namespace {
 
 constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chunk c, consumers on c-1, producers on c+2
 
-// Timing ablations for tools/ablate.py (never set in the shipped library): bit 0 skip stage cost,
-// 1 skip fp64 accumulation, 2 skip X stores, 3 skip control tile + control cost, 4 skip sincos,
-// 5 skip the gather, 6 skip the heading wrap.  Latency kernel only (tools/build_variant_fast.py <name> -DBN_ABLATE=..., timed with
-// BN_TOOL_LIB=<name> tools/region_overhead.py): 7 no ring writes, 9 consumers A and B skip their loops, 10 producers produce nothing,
-// 13 consumer A alone, 14 consumer B alone, 15 the position rows' wave, 16 consumer B only waits for the chain's end,
-// 17 consumer B starts its loop when the chain is through (tools/stamps_blog.py then shows its pace with every slot there).
-#ifndef BN_ABLATE
-#define BN_ABLATE 0
-#endif
-// Critical-path probes of the overlapped latency kernel (tools/variant_rate.py; results are WRONG with any bit set):
-// 1 column sums without the arithmetic, 2 softmin statistics without max / exp / sum, 4 merge without the arithmetic.
-#ifndef BN_VAR_SKIP
-#define BN_VAR_SKIP 0
-#endif
-#define BN_KEEP(v) asm volatile("" ::"v"(v))
-#ifdef BN_TIMING
-#define BN_STAMP(slot)                                                                                   \
-    do {                                                                                                 \
-        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { /* instance 0, workgroup 0 */ \
-            p.stamps[slot] = __builtin_readcyclecounter();                                               \
-            if ((slot) < 16) p.stamps[32 + ((p.solve & 1) << 4) + (slot)] = wall_clock64();   /* chip-wide 100 MHz clock, by solve parity (tools/stamps_overlap.py) */ \
-        }                                                                                                \
-    } while (0)
-#define BN_STAMP_ANY(slot)                                                                               \
-    do {                                                                                                 \
-        if (p.stamps && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[slot] = __builtin_readcyclecounter(); \
-    } while (0)
-// per-wave cycle stamps of workgroup 0 (tools/stamps_overlap.py): slot i of wave w at stamps[192 + 12 w + i]
-#define BN_WSTAMP(i)                                                                                     \
-    do {                                                                                                 \
-        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)                   \
-            p.stamps[192 + 12 * (threadIdx.x >> 6) + (i)] = __builtin_readcyclecounter();                \
-    } while (0)
-// per-workgroup trace (tools/block_trace.py): wall clock (100 MHz, chip-wide) at entry and exit, cycles, HW_ID
-#define BN_TRACE_BEGIN()                                                                                 \
-    const unsigned long long bn_tr_t0 = wall_clock64(), bn_tr_c0 = __builtin_readcyclecounter()
-#define BN_TRACE_END()                                                                                   \
-    do {                                                                                                 \
-        if (p.stamps && threadIdx.x == 0) {                                                              \
-            unsigned long long *r = p.stamps + 64 + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x + (p.trace_by_parity ? (size_t)(p.solve & 1) * gridDim.x * gridDim.y : 0));   \
-            r[0] = bn_tr_t0; r[1] = wall_clock64(); r[2] = __builtin_readcyclecounter() - bn_tr_c0;      \
-            r[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
-        }                                                                                                \
-    } while (0)
+// In-kernel time stamps and per-workgroup traces (BN_STAMP, BN_WSTAMP, BN_TRACE_*, BN_TIMING_DO(statements)): compiled in by the measurement builds only
+// (-DBN_EXPERIMENTS -DBN_TIMING, tools/stamps*.py, tools/block_trace*.py); csrc/experiments.h holds them, the shipped library sees
+// empty statements.  Round 5 took everything else of the lab bench out of the kernels: the ablation and critical-path switches
+// (BN_ABLATE, BN_VAR_*: compile-time bit tests inside the arithmetic) and the alternative cuts they selected are gone from the
+// sources -- the measurements they produced are in DESIGN_NOTEBOOK.md, the code that produced them in the history (round 4's head).
+#ifdef BN_EXPERIMENTS
+#include "experiments.h"
 #else
 #define BN_STAMP(slot) do { } while (0)
 #define BN_STAMP_ANY(slot) do { } while (0)
 #define BN_WSTAMP(i) do { } while (0)
 #define BN_TRACE_BEGIN() do { } while (0)
 #define BN_TRACE_END() do { } while (0)
+#define BN_TIMING_DO(...)
 #endif
 
 // Geometry specialisations of the cell index ((p - origin) / res).floor().int()  (grid_map.py:195-209):
@@ -82,7 +37,7 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 enum Geo : int { kGeoGeneral = 0, kGeoPow2 = 1, kGeoPow2Origin0 = 2 };
 
 struct Win { int wx0, wy0; float fx0, fy0, fwn, fwm1; int wn;
-             // the latency kernel's chain wave (BN_CHAIN_ASM2): constants it keeps in vector registers of its own -- left to the compiler
+             // the latency kernel's chain wave: constants it keeps in vector registers of its own -- left to the compiler
              // they are re-materialised from scalar registers in every chunk
              float xhi_v, yhi_v; v2f c0_v; };   // window origin (cells), as floats, edge, edge-1, edge
 
@@ -217,7 +172,6 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
     } else {
         q = quotient_general(p, xy - v2f{p.x0, p.y0}) + nw;
     }
-#ifdef BN_CHAIN_ASM2
     if (ASMIDX == 2 && GEO != kGeoGeneral) {
         // The latency kernel's chain wave (ASMIDX = 2; the tail's X* rollout keeps ASMIDX = 1 below: fixed registers at the top of
         // a 128-register budget would cost the role kernel, whose aux workgroup runs that tail, its occupancy).  The same five instructions -- quotient (packed FMA), floor-and-convert x 2, row * WN + col, byte address -- as ONE asm
@@ -239,7 +193,6 @@ __device__ __forceinline__ float trav_window(const SolveParams &p, const float *
             : "=v"(addr) : "v"(xyo), "s"(ir), "v"(nw), "s"(w.wn), "s"(base) : "v126", "v127");
         return *(lds_cf *)(uintptr_t)addr;
     }
-#endif
     if (ASMIDX == 1 || ASMIDX == 3) {
         // The latency kernel's chain wave: floor-and-convert in one instruction, row * WN + col as one v_mad_u32_u24 (left to itself
         // the compiler spreads the *4 of the byte address over both terms).  Same integers.  8.65 -> 8.57 us per dependent solve;
@@ -316,18 +269,11 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
     const v2f pos = __builtin_elementwise_fma(v2f{c.trav, c.trav}, c.G, v2f{c.x, c.y});   // :86-87, x and y in lockstep
     xn = pos.x;
     yn = pos.y;
-#ifdef BN_CHAIN_ASM2
     c.x = clampf(xn, p.x0, ASMIDX >= 2 ? w.xhi_v : p.x_hi);            // :93   (ASMIDX 2, 3: the upper limits in vector registers the caller keeps)
     c.y = clampf(yn, p.y0, ASMIDX >= 2 ? w.yhi_v : p.y_hi);            // :94
-#else
-    c.x = clampf(xn, p.x0, p.x_hi);                                    // :93
-    c.y = clampf(yn, p.y0, p.y_hi);                                    // :94
-#endif
-    if (BN_ABLATE & 32) { c.trav = 0.5f + 0.001f * c.x; } else
     c.trav = LDSWIN ? trav_window<GEO, ASMIDX>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
     __builtin_amdgcn_sched_barrier(0);
     if (THETA) tn = theta_step(c.th, dth, FIRST); else tn = dth;
-    if (BN_ABLATE & 16) { c.sn = c.sn * 0.5f + dth; c.cs = 1.0f - c.sn; } else
     rotate_spec<ASMIDX == 2>(c.cs, c.sn, dth, w.c0_v);
     if (PREP) chain_prepare(p, c, u0n, u1n);
 }
@@ -526,9 +472,6 @@ __device__ __forceinline__ void raise_wait_expired(const SolveParams &p, const u
 }
 __device__ __forceinline__ bool batch_spoiled(const SolveParams &p)
 {
-#ifdef BN_NO_SPOIL_GUARD                              // experiments (tools/recovery_stress.py): the behaviour before the guard
-    return false;
-#endif
     return p.err_dev != nullptr && __hip_atomic_load(p.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
@@ -590,10 +533,8 @@ __device__ __forceinline__ void column_sums(const float *Ul, const float *el, in
         const int j = it >> 2, r = it & 3;
         const float *col = Ul + j * kUPad + 16 * r, *e = el + 16 * r;
         float acc = 0.0f;
-        if (BN_VAR_SKIP & 1) acc = e[0] * col[0]; else
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc = __builtin_fmaf(e[q], col[q], acc);
-        if (!(BN_VAR_SKIP & 1))
         asm volatile("s_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
                      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1"
@@ -791,7 +732,6 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 #define BN_SCALE(i) __int_as_float(__builtin_amdgcn_readlane(fb, (i)))
         for (int jj = col; jj < 2 * T; jj += NT) {
             float acc = 0.0f;
-            if (BN_VAR_SKIP & 4) { us[jj] = L.v[0] * 1e-3f; continue; }
             int i0 = 0;
             if (jj == L.j) {
 #pragma unroll

@@ -8,10 +8,7 @@ namespace bn {
 
 constexpr int kRolloutsPerBlock = 64;   // lane = rollout; 64 rollouts per workgroup
 constexpr int kRolloutThreads = 320;    // 5 wavefronts per workgroup, specialised by role (chain / 2 producers / 2 consumers)
-#ifndef BN_CHUNK
-#define BN_CHUNK 4                       // experiments: tools/build_variant.py x -DBN_CHUNK=8 (the latency kernel is left out then)
-#endif
-constexpr int kChunk = BN_CHUNK;                // time steps per barrier phase of the rollout kernel
+constexpr int kChunk = 4;                // time steps per barrier phase of the rollout kernel (8 was measured slower, round 2)
 constexpr int kWaveParkSteps = 30;       // == kParkSteps of wave_park.h (static_assert in rollout_wave.hip)
 constexpr int kUPad = 65;               // LDS row pitch of the control tile (bank-conflict-free both ways)
 constexpr int kWideFinishThreads = 1024;           // stand-alone tail of the sizes that are not pipelined (K > 2048)

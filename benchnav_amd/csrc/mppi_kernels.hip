@@ -435,7 +435,7 @@ hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
 size_t wave_lds_bytes(const SolveParams &p)
 {
     const size_t own = (size_t)p.WN * p.WN + 6 * (size_t)p.T + 16 + 64 + (size_t)p.nblk + 32 + 16 * kUPad;   // + the epilogue's control tile (kRegenCols columns)
-#ifdef BN_WAVE_LDS_PAD                                 // experiments (tools/build_variant_wave.py): fewer workgroups per CU
+#if defined(BN_EXPERIMENTS) && defined(BN_WAVE_LDS_PAD)      // measurement builds (csrc/experiments.h): fewer workgroups per CU
     return std::max(sizeof(float) * own, finish_lds_bytes(p) + 256) + BN_WAVE_LDS_PAD;
 #endif
     return std::max(sizeof(float) * own, finish_lds_bytes(p) + 256);      // the aux workgroup runs finish_body in the same LDS

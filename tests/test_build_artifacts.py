@@ -139,3 +139,55 @@ def test_parked_register_block_is_touched_by_its_two_statements_only(tmp_path):
             else:
                 assert all(r < base for r in regs), f"{cur}: `{t}` touches the parked block (v{base}..)"
     assert seen == len(park) and brackets >= 2 * seen, (seen, brackets)
+
+
+@pytest.mark.skipif(not (os.path.exists(f"{LLVM}/llvm-objdump") and os.path.exists(f"{LLVM}/clang-offload-bundler")), reason="ROCm LLVM tools not installed")
+def test_latency_kernel_scratch_registers_belong_to_its_two_asm_blocks(tmp_path):
+    """The latency kernel's chain wave runs its gather address and its heading rotation as one asm block each, with v124-v127 as
+    fixed scratch registers (csrc/mppi_device.h trav_window<.., 2>, csrc/bn_device_math.h rotate_spec<true>).
+    In the SHIPPED code objects every instruction that names one of the four is an instruction of those blocks -- by opcode, and in
+    the blocks' proportions (one gather block = 1 v_pk_fma + 2 v_cvt_flr + 1 v_mad_u32_u24 + 1 v_lshl_add; one rotation block =
+    2 v_mul + 4 v_pk_fma + 1 v_pk_mul) -- and the two kinds come in pairs (one of each per unrolled step; rotation blocks alone
+    in the general-resolution variants).  A compiler that began to
+    allocate those registers for its own values around the blocks would show up here as a foreign opcode or a broken proportion."""
+    from benchnav_amd import _capi
+    from benchnav_amd import build as b
+    _capi.load()
+    allowed = ("v_mul_f32", "v_cvt_flr_i32_f32", "v_pk_mul_f32", "v_pk_fma_f32", "v_mad_u32_u24", "v_lshl_add_u32")
+    seen, both = 0, 0
+    for co in _code_objects(b.LIB_PATH, str(tmp_path)):
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+        cur, counts = None, None
+
+        def close(name, c):
+            if name is None:
+                return
+            r, g = c.get("v_pk_mul_f32", 0), c.get("v_mad_u32_u24", 0)      # rotation blocks, gather blocks
+            # (general resolutions keep the compiler's gather: rotation blocks only; the reference-order variants evaluate sin / cos of
+            # every heading instead of rotating: gather blocks only)
+            assert (r == g or min(r, g) == 0) and (max(r, g) >= 4 or not c), (name, c)      # (general resolution AND reference order: neither block)
+            nonlocal both
+            both += (r > 0 and g > 0)
+            assert c.get("v_cvt_flr_i32_f32", 0) == 2 * g and c.get("v_lshl_add_u32", 0) == g, (name, c)
+            assert c.get("v_mul_f32", 0) == 2 * r and c.get("v_pk_fma_f32", 0) == 4 * r + g, (name, c)
+
+        for line in dis.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                close(cur, counts)
+                cur = m.group(1) if "rollout_lat_kernel" in m.group(1) else None
+                counts = {}
+                seen += cur is not None
+                continue
+            if cur is None:
+                continue
+            t = line.split("//")[0].strip()
+            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", t)]
+            for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", t):
+                regs += list(range(int(lo), int(hi) + 1))
+            if any(124 <= r <= 127 for r in regs):
+                op = next((a for a in allowed if t.startswith(a)), None)
+                assert op is not None, f"{cur}: `{t}` names a scratch register of the chain wave's asm blocks"
+                counts[op] = counts.get(op, 0) + 1
+        close(cur, counts)
+    assert seen >= 12 and both >= 6, (seen, both)
