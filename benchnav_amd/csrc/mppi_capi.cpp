@@ -547,6 +547,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     if (const char *e = exp_env("BN_REGEN_STEPS")) p.regen_steps = std::max(0, atoi(e));      // experiments: tools/wave_ab.py
     if (const char *e = exp_env("BN_PARK_STEPS")) p.park_steps = std::min(std::max(0, atoi(e)), bn::kWaveParkSteps);
     p.ref_order = ((cfg->flags & BN_FLAG_REFERENCE_ORDER) || big_step) ? 1 : 0;
+    p.wrap_near = ((double)cfg->dt * std::max(std::fabs((double)cfg->u_min[1]), std::fabs((double)cfg->u_max[1])) < 3.0) ? 1 : 0;
     // Workgroup i of a launch runs on XCD i % 8 (observed, used for speed only).  xs = 3 interleaves 8 instances along grid x
     // so that the workgroups of one instance share an XCD's L2 (rollout_grid); measured SLOWER (64 instances: 29.2 vs 28.1 us,
     // 60: 28.5 vs 24.9): the dispatcher then fills the CUs unevenly (3 to 5 workgroups per CU instead of 4, tools/block_trace.py)

@@ -249,16 +249,23 @@ __device__ __forceinline__ void chain_step(const SolveParams &p, const float *wi
 {
     if constexpr (REF) {
         static_assert(THETA && !PREP, "the reference-order step integrates its own heading");
-        float sn, cs;
-        sincos_spec(c.th, sn, cs);
+        // (c.sn, c.cs) = sincos_spec(c.th) on entry and on exit: every caller sets them with the start heading, and the step ends with
+        // the sine and cosine of the NEXT heading, issued behind the next gather.  After the first step the heading wrap takes the
+        // branch-free near form where it is valid (p.wrap_near: dt max|omega| < 3; bit-identical to the general form there,
+        // tests/test_gpu_device_math.py).  Same operations per value as before (round 5) -- and the same 11.7 us per
+        // dependent single-instance solve: the chain wave is alone on its SIMD and issues one instruction per ~5 cycles whatever
+        // they wait for, so its 46 instructions per step ARE the step (the default arithmetic has 25); the gather's latency was
+        // already covered.  The price of this arithmetic on the latency path stays 1.36x; `value_reference_order` reports it.
         const float tv = c.trav * u0;
-        xn = c.x + (tv * cs) * p.dt;                                   // :86
-        yn = c.y + (tv * sn) * p.dt;                                   // :87
+        xn = c.x + (tv * c.cs) * p.dt;                                 // :86
+        yn = c.y + (tv * c.sn) * p.dt;                                 // :87
         tn = c.th + (c.trav * u1) * p.dt;                              // :88
-        c.th = wrap_angle(tn);                                         // :90
         c.x = clampf(xn, p.x0, ASMIDX >= 2 ? w.xhi_v : p.x_hi);        // :93
         c.y = clampf(yn, p.y0, ASMIDX >= 2 ? w.yhi_v : p.y_hi);        // :94
         c.trav = LDSWIN ? trav_window<GEO, ASMIDX>(p, win, w, c.x, c.y) : trav_lookup<GEO, false, false>(p, win, map, w, c.x, c.y);
+        __builtin_amdgcn_sched_barrier(0);
+        c.th = (!FIRST && p.wrap_near) ? wrap_angle_near(tn) : wrap_angle(tn);      // :90
+        sincos_spec(c.th, c.sn, c.cs);
         return;
     }
     if (!PREP) chain_prepare(p, c, u0, u1);

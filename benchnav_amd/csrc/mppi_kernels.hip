@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void reroll_kernel(const SolveParams p, int b,
             noise_pair<EPS>(p, b, k, t, e);
             const float u0 = clampf(ml[2 * t] + p.sigma0 * e[0], p.umin0, p.umax0);          // mppi.py:152-157
             const float u1 = clampf(ml[2 * t + 1] + p.sigma1 * e[1], p.umin1, p.umax1);
-            if (ref) chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+            if (ref && t == 0) chain_step<GEO, LDSWIN, true, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);      // (FIRST: the general heading wrap)
+            else if (ref) chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
             else if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
             else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, u0, u1, xn, yn, tn);
             Xo[3 * t] = xn; Xo[3 * t + 1] = yn; Xo[3 * t + 2] = tn;
@@ -173,7 +174,8 @@ __global__ void dwa_kernel(const SolveParams p, const float *__restrict__ action
     const bool ref = p.ref_order != 0;
     for (int t = 0; t < T; ++t) {
         float xn, yn, tn;
-        if (ref) chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+        if (ref && t == 0) chain_step<GEO, LDSWIN, true, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
+        else if (ref) chain_step<GEO, LDSWIN, false, true, false, 0, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
         else if (t == 0) chain_step<GEO, LDSWIN, true>(p, win, map, w, c, u0, u1, xn, yn, tn);
         else chain_step<GEO, LDSWIN, false>(p, win, map, w, c, u0, u1, xn, yn, tn);
         if (Xk && active) { Xk[3 * t] = xn; Xk[3 * t + 1] = yn; Xk[3 * t + 2] = tn; }
