@@ -408,6 +408,8 @@ def main():
 
     if extras:
         def leg(pl_, st_, ring_, n_):
+            if os.environ.get("BENCH_DEBUG"):
+                print(f"[leg] B={pl_.B} K={pl_.K} T={pl_.T} n={n_}", file=sys.stderr, flush=True)
             timed_solves(pl_, st_, ring_, kind, 30, torch.cuda.synchronize)
             best = None
             for _ in range(3):

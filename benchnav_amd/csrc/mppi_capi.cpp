@@ -546,6 +546,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
     p.park_steps = bn::kWaveParkSteps;
     if (const char *e = exp_env("BN_REGEN_STEPS")) p.regen_steps = std::max(0, atoi(e));      // experiments: tools/wave_ab.py
     if (const char *e = exp_env("BN_PARK_STEPS")) p.park_steps = std::min(std::max(0, atoi(e)), bn::kWaveParkSteps);
+    p.lds_park = 0;                                    // decided below, when the window is known
     p.ref_order = ((cfg->flags & BN_FLAG_REFERENCE_ORDER) || big_step) ? 1 : 0;
     p.wrap_near = ((double)cfg->dt * std::max(std::fabs((double)cfg->u_min[1]), std::fabs((double)cfg->u_max[1])) < 3.0) ? 1 : 0;
     // Workgroup i of a launch runs on XCD i % 8 (observed, used for speed only).  xs = 3 interleaves 8 instances along grid x
@@ -625,6 +626,11 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
                            ((cfg->flags & BN_FLAG_WAVE_KERNEL) ||
                             (((size_t)p.B + 1) * (p.nblk + 1) > (size_t)h->n_cus && wave_kernel_is_faster(p, h->resident_wgs, h->n_cus)));
     if (p.store_u || want_wave || h->slow_path) alloc(&h->d_U, B * T * 2 * (size_t)p.Kp * 4);
+    // one-wave kernel: a second control tile in LDS for the chunk behind the register block, if 16 workgroups per CU still fit
+    if (want_wave && p.park_steps > 0 && p.regen_steps > 0 && p.WN > 0 && !exp_env("BN_NO_LDS_PARK")) {
+        p.lds_park = 1;
+        if (bn::wave_lds_bytes(p) > (size_t)160 * 1024 / 16) p.lds_park = 0;
+    }
     for (int q = 0; q < kSlots; ++q) {
         alloc(&h->d_cost[q], B * K * 4);
         alloc(&h->d_part[q], B * (size_t)p.nblk * (2 + 2 * T) * 4);

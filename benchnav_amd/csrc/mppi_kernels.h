@@ -41,6 +41,7 @@ struct SolveParams {
                          // round trip through the control buffer (what injected noise always does): VALU against HBM traffic
     int park_steps;      // one-wave kernel: the controls of steps [0, park_steps) wait for their weights in registers of the lane (rollout_wave.inc,
                          // wave_park.h; at most kWaveParkSteps), 0 = the kernel without the register block
+    int lds_park;        // one-wave kernel: one more chunk of eight steps waits for its weights in an LDS tile (set when it keeps 16 workgroups per CU)
     int wrap_near;       // reference-order transit: dt * max|omega| < 3 rad, so every heading after the first step's wrap lies where the
                          // branch-free form of the wrap (wrap_angle_near) equals torch.remainder's bit for bit
     int lean;            // lean mode: the (K,T+1,3) trajectory batch is not materialised (bn_mppi_reroll regenerates rows on demand)

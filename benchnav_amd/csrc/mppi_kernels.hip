@@ -436,7 +436,10 @@ hipError_t launch_finish_t(const SolveParams &p, hipStream_t s)
 
 size_t wave_lds_bytes(const SolveParams &p)
 {
-    const size_t own = (size_t)p.WN * p.WN + 6 * (size_t)p.T + 16 + 64 + (size_t)p.nblk + 32 + 16 * kUPad;   // + the epilogue's control tile (kRegenCols columns)
+    // [ A = max(window + (mean, mean @ inv_cov) rows, the epilogue's tile over them) | mean 2T | e 64 | merge scratch | parked chunk's tile ]
+    const size_t wn_f = ((size_t)p.WN * p.WN + 3) & ~(size_t)3;
+    const size_t own = std::max(wn_f + 4 * ((size_t)p.T + 1), (size_t)16 * kUPad + 4) + 2 * (size_t)p.T + 4 + 64 + (size_t)p.nblk + 32 + 4 +
+                       (p.lds_park ? (size_t)16 * kUPad : 0);
 #if defined(BN_EXPERIMENTS) && defined(BN_WAVE_LDS_PAD)      // measurement builds (csrc/experiments.h): fewer workgroups per CU
     return std::max(sizeof(float) * own, finish_lds_bytes(p) + 256) + BN_WAVE_LDS_PAD;
 #endif

@@ -12,7 +12,7 @@ G, K, T, RES = 256, 1024, 50, 0.5
 lean = case.endswith("_lean")
 base = case.replace("_lean", "")
 torch.set_num_threads(1)
-if base in ("B1", "B64", "B256"):
+if base in ("B1", "B8", "B64", "B256"):
     B = int(base[1:])
     insts = [synth.make_instance(G, seed=s, resolution=RES, jitter=B > 1) for s in range(min(B, 64))]
     shared = B > 64 or B == 1
