@@ -40,7 +40,11 @@ bool wave_kernel_is_faster(const bn::SolveParams &p, size_t resident_role_wgs, i
 {
     const double W = (double)p.B * (p.nblk + 1), R = (double)std::max<size_t>(resident_role_wgs, 1), rows = std::max(0, p.nblk - 16);
     const double role = (4.5 + 0.19 * p.T + 0.3 * rows) * (1.0 + 0.175 * std::min(W, R) / std::max(n_cus, 1)) * std::max(1.0, W / R);
-    const double wave = (3.3 + 0.44 * p.T + 0.37 * rows) * (1.0 + 1.5 * W / (24.0 * std::max(n_cus, 1)));
+    // (round 5: x 0.93 -- the one-wave kernel lost a quarter of its instructions; re-checked against tools/auto_sweep.py, which had
+    // flagged K=1024 T=50 at 80 instances and K=512 T=20 at 128 where the role kernel spills into a second residency round)
+    // (not for short horizons or more than 16 workgroups per instance, where the sweep has the role kernel ahead at the old crossover)
+    const double gain = (rows == 0 && p.T >= 20) ? 0.93 : 1.0;
+    const double wave = gain * (3.3 + 0.44 * p.T + 0.37 * rows) * (1.0 + 1.5 * W / (24.0 * std::max(n_cus, 1)));
     return wave < role;
 }
 thread_local std::string g_last_error;
