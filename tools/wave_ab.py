@@ -16,13 +16,14 @@ def child(name):
     from benchnav_amd import NativeMPPI, synth
     torch.set_num_threads(1)
     ref = os.environ.get("BN_REF", "0") == "1"
+    ov = os.environ.get("BN_OVERLAP", "1") == "1"      # BN_OVERLAP=0: every launch on one stream (what rocprofv3 times per kernel)
     digests = []
     for lean in (False, True):
         h = hashlib.sha256()
         B = 20
         insts = [synth.make_instance(256, seed=b) for b in range(B)]
         st = torch.stack([it.start for it in insts]).cuda()
-        pl = NativeMPPI(horizon=50, num_samples=1000, grid_size=256, resolution=0.5, num_instances=B, lean=lean, kernel="wave", reference_order=ref)
+        pl = NativeMPPI(horizon=50, num_samples=1000, grid_size=256, resolution=0.5, num_instances=B, lean=lean, kernel="wave", reference_order=ref, overlap=ov)
         for b, it in enumerate(insts):
             pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
         pl.solve_n_async_device(3, st.data_ptr()); pl.sync()
@@ -38,7 +39,7 @@ def child(name):
         insts = [synth.make_instance(256, seed=b) for b in range(B)]
         st = torch.stack([it.start for it in insts]).cuda()
         for lean in (False, True):
-            pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, num_instances=B, lean=lean, kernel="wave", reference_order=ref)
+            pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, num_instances=B, lean=lean, kernel="wave", reference_order=ref, overlap=ov)
             for b, it in enumerate(insts):
                 pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
             pl.solve_n_async_device(50, st.data_ptr()); pl.sync()
