@@ -43,6 +43,30 @@ def test_wave_kernel_chain_equals_role_kernel_chain(K, T, B, noise):
             assert np.array_equal(a_, b_), (b, j)
 
 
+@pytest.mark.parametrize("lean", [False, True], ids=["full", "lean"])
+@pytest.mark.parametrize("T", [1, 2, 3, 8, 9, 29, 30, 31, 32, 33, 35, 39, 40, 41, 49, 63, 100])
+def test_parked_controls_over_the_horizon(T, lean):
+    """Round 5: the one-wave kernel keeps the controls of its first 30 steps in the lane's own registers (VGPR index mode), one more
+    chunk of eight in an LDS tile, and draws the rest again.  Every boundary of that arrangement -- horizons below, at and just above
+    the register block, a partial and an odd LDS-parked chunk, horizons far beyond both -- against the role kernel, which has none
+    of it: costs, weights, warm start and (with the trajectory dump) every state must be bit-identical, Philox noise, ragged K."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    K, B, G, n = 130, 3, 64, 3
+    insts = [synth.make_instance(G, seed=40 + b, jitter=True) for b in range(B)]
+    st = torch.stack([it.start for it in insts]).cuda()
+    res = {}
+    for kern in ("role", "wave"):
+        with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, seed=11, kernel=kern, lean=lean) as pl:
+            for b, it in enumerate(insts):
+                pl.set_map(it.risk.numpy(), b); pl.set_goal(it.goal.numpy(), b)
+            pl.solve_n_async_device(n, st.data_ptr()); pl.sync()
+            res[kern] = [(pl.costs(b), pl.weights(b), pl.get_mean(b), pl.states(b)) for b in range(B)]
+    for b in range(B):
+        for j, (a_, b_) in enumerate(zip(res["wave"][b], res["role"][b])):
+            assert np.array_equal(a_, b_), (T, lean, b, j)
+
+
 def test_wave_kernel_matches_oracle_and_is_the_default_for_large_batches():
     from oracle import oracle as O
     from benchnav_amd import NativeMPPI, synth
