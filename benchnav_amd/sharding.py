@@ -141,10 +141,23 @@ class ShardedMPPI:
         # here: 60 us per solve on one rank).  The communicator's id travels over the group the job has anyway.
         self._fused = False
         if self._direct and self._dist is not None and os.environ.get("BN_SHARD_TORCH_COLLECTIVE") != "1":
-            box = [unique_id() if self.rank == 0 else None]
+            # ... and every rank must end up on the same path: whoever fails (no librccl to open, communicator refused) makes all of them
+            # keep torch's collective -- agreed with one all-reduce, so that no rank waits in a collective the others never enter
+            try:
+                box = [unique_id() if self.rank == 0 else None]
+            except Exception:
+                box = [None]
             self._dist.broadcast_object_list(box, src=self._dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            self.planner.shard_comm_init(box[0], self.world, self.rank)
-            self._fused = True
+            ok = 0
+            if box[0] is not None:
+                try:
+                    self.planner.shard_comm_init(box[0], self.world, self.rank)
+                    ok = 1
+                except Exception:
+                    ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN, group=group)
+            self._fused = bool(int(flag.item()))
 
     def _view(self, ptr, shape):
         from .mppi import _DevArray
