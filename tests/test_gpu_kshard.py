@@ -85,6 +85,40 @@ def test_shard_protocol_errors():
             pl.shard_rollout_async_device(torch.stack([st, st]).data_ptr())
 
 
+def test_library_enqueued_exchange_protocol_and_results():
+    """bn_mppi_shard_solve_async (round 5): needs the communicator first, refuses a second one and a rank outside the world; with a
+    communicator of one rank (no torch process group involved: the id is drawn and consumed in this process) three warm-started
+    solves are bit-identical to the three-call protocol on a second handle, and every result getter sees the side-stream tail."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    from benchnav_amd.sharding import unique_id
+    K, T, G = 2048, 33, 128
+    inst = synth.make_instance(G, seed=6)
+    st = inst.start.cuda()
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=5, stream=0) as a, \
+         NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=5, stream=0) as b:
+        for pl in (a, b):
+            pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+        with pytest.raises(RuntimeError, match="shard_comm_init must precede"):
+            a.shard_solve_async_device(st.data_ptr())
+        uid = unique_id()
+        assert len(uid) == 128
+        with pytest.raises(RuntimeError, match="outside a world"):
+            a.shard_comm_init(uid, 1, 1)
+        a.shard_comm_init(uid, 1, 0)
+        with pytest.raises(RuntimeError, match="communicator already"):
+            a.shard_comm_init(unique_id(), 1, 0)
+        for i in range(3):
+            a.shard_solve_async_device(st.data_ptr())
+            b.shard_rollout_async_device(st.data_ptr())
+            ptr, n, ps = b.shard_partials()
+            b.shard_finish_async(ptr, n)
+            for what in ("get_mean", "weights", "costs"):            # (each getter orders the handle's stream behind the side-stream tail)
+                assert np.array_equal(getattr(a, what)(), getattr(b, what)()), (i, what)
+        a.sync(); b.sync()
+        assert np.array_equal(a.states(), b.states())
+
+
 def _dist_worker(rank, world, port, q):
     import os
     import torch
