@@ -118,12 +118,23 @@ __device__ __forceinline__ Win window_origin(const SolveParams &p, float sx, flo
 __device__ __forceinline__ void stage_window(float *win, const float *__restrict__ map, const Win w,
                                              int WN, int G, int tid, int nthreads)
 {
+    // Four cells per thread and round trip: written as one cell per iteration the loop is load - wait - store, a full memory round trip
+    // per 320 cells, in the prologue of every launch and of every tail (round 5: the headline's 24 x 24 window took two).
     const int n = WN * WN;
-    for (int e = tid; e < n; e += nthreads) {
-        const int r = e / WN;
-        const int c = e - r * WN;
-        const float risk = map[(size_t)min(w.wy0 + r, G - 1) * G + min(w.wx0 + c, G - 1)];      // (the guard row / column: index G -> G-1)
-        win[e] = 1.0f - clampf(risk, 0.0f, 1.0f);
+    for (int e0 = tid; e0 < n; e0 += 4 * nthreads) {
+        float risk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = min(e0 + i * nthreads, n - 1);       // (behind the window: the last cell again, not stored)
+            const int r = e / WN;
+            const int c = e - r * WN;
+            risk[i] = map[(size_t)min(w.wy0 + r, G - 1) * G + min(w.wx0 + c, G - 1)];      // (the guard row / column: index G -> G-1)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + i * nthreads;
+            if (e < n) win[e] = 1.0f - clampf(risk[i], 0.0f, 1.0f);
+        }
     }
 }
 
@@ -834,10 +845,18 @@ template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false, bo
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
                                             const float *state_all, float *smem)
 {
+    // Tails of consecutive overlapped solves write the same output buffers, so they are ordered by a counter.  What has to be ordered are
+    // the STORES: with the wait in front of everything (rounds 3-4) a tail started when its predecessor was through, and at ~8.5 us a
+    // tail (two dependent fetches, the merge, the 50-step rollout of U*) the chain of tails, not the rollouts, set the period of a batch
+    // of dependent solves (tools/block_trace_lat.py: the aux workgroup left its launch 4 us after the rollout workgroups).  Open loop,
+    // the waves that write (1 ..) wait for the tail before this one just before their first store, behind the merge; wave 0 rolls U*
+    // out into LDS meanwhile and meets them at the barrier in front of its own stores.  (Episodes: the environment step reads what the
+    // previous tail wrote -- the wait stays in front.)
+    const bool defer_tail_wait = AGENT && NT > 64 && !p.env_on && !p.slip_on && !p.tail_merged;
     if (AGENT) {
         if (threadIdx.x == 0) {
             wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p);   // the solve whose tail this is has published everything
-            wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);               // and the tail before it has left the output buffers
+            if (!defer_tail_wait) wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);   // and the tail before it has left the output buffers
         }
         __syncthreads();
     }
@@ -880,23 +899,29 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         __syncthreads();
     } else {
         merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
-        const bool spoiled = batch_spoiled(p);                 // a wait of this stretch expired: nothing merged since may reach `mean`
-        for (int j = tid; j < 2 * T; j += NT) {
-            st<AGENT>(p.ustar + (size_t)b * 2 * T + j, us[j]);
-            if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, us[j]);
-            if (spoiled) continue;
-            if (p.mean_used) st<AGENT>(p.mean_used + (size_t)b * 2 * T + j, ld<AGENT>(p.mean + (size_t)b * 2 * T + j));   // what this solve sampled around
-            st<AGENT>(p.mean + (size_t)b * 2 * T + j, us[j]);  // _previous_action_seq = U*, no shift (mppi.py:217)
-        }
     }
-    if (tid == 0) {
-        if (p.mail) {                                  // the first control of U*, for the host that waits for it: out before anything else
-            store_granule_host(p.mail + 2 * b, us[0], (uint32_t)p.tail_solve + 1u);
-            store_granule_host(p.mail + 2 * b + 1, us[1], (uint32_t)p.tail_solve + 1u);
+    // U*, the next mean, the statistics: threads j0, j0 + step, .. (all of them, or -- deferred wait -- the writing waves behind their wait)
+    auto store_ustar = [&](int j0, int step, bool first) {
+        if (!p.tail_merged) {
+            const bool spoiled = batch_spoiled(p);             // a wait of this stretch expired: nothing merged since may reach `mean`
+            for (int j = j0; j < 2 * T; j += step) {
+                st<AGENT>(p.ustar + (size_t)b * 2 * T + j, us[j]);
+                if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, us[j]);
+                if (spoiled) continue;
+                if (p.mean_used) st<AGENT>(p.mean_used + (size_t)b * 2 * T + j, ld<AGENT>(p.mean + (size_t)b * 2 * T + j));   // what this solve sampled around
+                st<AGENT>(p.mean + (size_t)b * 2 * T + j, us[j]);  // _previous_action_seq = U*, no shift (mppi.py:217)
+            }
         }
-        st<AGENT>(p.stats + b * 2 + 0, m);
-        st<AGENT>(p.stats + b * 2 + 1, S);
-    }
+        if (first) {
+            if (p.mail) {                              // the first control of U*, for the host that waits for it: out before anything else
+                store_granule_host(p.mail + 2 * b, us[0], (uint32_t)p.tail_solve + 1u);
+                store_granule_host(p.mail + 2 * b + 1, us[1], (uint32_t)p.tail_solve + 1u);
+            }
+            st<AGENT>(p.stats + b * 2 + 0, m);
+            st<AGENT>(p.stats + b * 2 + 1, S);
+        }
+    };
+    if (!defer_tail_wait) store_ustar(tid, NT, tid == 0);
     if (p.env_on && tid == 64) {
         // the environment step that follows this solve: apply U*[0], log state, reward and goal arrival
         const EnvStep e = env_advance<GEO>(p, b, sx, sy, sth, us[0], us[1], p.env_z, (uint64_t)p.ep_index);
@@ -1050,6 +1075,10 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         Xs[3 * T + 0] = c.x; Xs[3 * T + 1] = c.y; Xs[3 * T + 2] = c.th;
         BN_STAMP(11);
     } else if (NT > 64 && tid >= 64) {
+        if (defer_tail_wait) {                         // every writing wave waits for itself: wave 0 is on the serial rollout, no barrier to meet at
+            if ((tid & 63) == 0) wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);
+            store_ustar(tid - 64, NT - 64, tid == 64);
+        }
         // _weights = softmax(-costs / lambda)   mppi.py:193
         const float *cost = cost_all + (size_t)b * K;
         float *wout = p.w + (size_t)b * K;
