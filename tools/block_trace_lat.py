@@ -9,7 +9,7 @@ from benchnav_amd import build as b
 b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ.get("BN_VARIANT", "timing"))
 from benchnav_amd import NativeMPPI, synth
 inst = synth.make_instance(256, seed=0)
-pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, kernel="lat")
+pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, kernel="lat", reference_order=bool(int(os.environ.get("BN_REF", "0"))))
 pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
 nb = 32
 stamps = torch.zeros(64 + 4 * 2 * nb + 64, dtype=torch.int64, device="cuda")
@@ -25,8 +25,8 @@ for rep in range(15):
     total = pl.solve_count()
     r = stamps.cpu().numpy()[64:64 + 4 * 2 * nb].reshape(2, nb, 4).astype(np.float64)
     last, prev = r[(total - 1) & 1], r[(total - 2) & 1]
-    base = prev[:16, 0].min()
-    f = lambda rr: [(rr[:16, 0].min() - base) / 100, (rr[:16, 0].max() - base) / 100, (rr[:16, 1].min() - base) / 100, (rr[:16, 1].max() - base) / 100,
+    base = prev[:16, 0][prev[:16, 0] > 0].min()
+    f = lambda rr: [(rr[:16, 0][rr[:16, 0] > 0].min() - base) / 100, (rr[:16, 0].max() - base) / 100, (rr[:16, 1][rr[:16, 1] > 0].min() - base) / 100, (rr[:16, 1].max() - base) / 100,
                     (rr[16, 0] - base) / 100 if rr[16, 1] else np.nan, (rr[16, 1] - base) / 100 if rr[16, 1] else np.nan]
     rows.append(f(prev) + f(last))
 m = np.nanmedian(np.array(rows), axis=0)

@@ -10,6 +10,7 @@ args = sys.argv[1:]
 timing = "--timing" in args
 args = [a for a in args if a != "--timing"]
 name, flags = args[0], args[1:]
+SRC = os.environ.get("BN_VARIANT_SRC", "rollout_role_philox.hip")      # the one kernel source compiled with the extra flags
 out_dir = os.path.join(ROOT, "tools", "_ablate")
 os.makedirs(out_dir, exist_ok=True)
 compile_flags = [f for f in b.HIPCC_FLAGS if f != "-shared"] + ["-DBN_EXPERIMENTS"]
@@ -18,19 +19,19 @@ if timing:
     flags = ["-DBN_TIMING"] + flags
     base_dir = os.path.join(out_dir, "obj_timing")
     os.makedirs(base_dir, exist_ok=True)
-    stale = [s for s in b.SOURCES if s != "rollout_role_philox.hip" and
+    stale = [s for s in b.SOURCES if s != SRC and
              (not os.path.exists(os.path.join(base_dir, os.path.splitext(s)[0] + ".o")) or
               os.path.getmtime(os.path.join(base_dir, os.path.splitext(s)[0] + ".o")) < max(os.path.getmtime(os.path.join(b.CSRC, f)) for f in os.listdir(b.CSRC)))]
     procs = [subprocess.Popen([b.hipcc(), *compile_flags, "-DBN_TIMING", "-x", "hip", "-c", os.path.join(b.CSRC, s), "-o",
                                os.path.join(base_dir, os.path.splitext(s)[0] + ".o")]) for s in stale]
     for pr in procs:
         assert pr.wait() == 0
-obj = os.path.join(out_dir, f"role_philox_{name}.o")
-subprocess.check_call([b.hipcc(), *compile_flags, *flags, "-x", "hip", "-c", os.path.join(b.CSRC, "rollout_role_philox.hip"), "-o", obj])
+obj = os.path.join(out_dir, f"{os.path.splitext(SRC)[0]}_{name}.o")
+subprocess.check_call([b.hipcc(), *compile_flags, *b.EXTRA_FLAGS.get(SRC, []), *flags, "-x", "hip", "-c", os.path.join(b.CSRC, SRC), "-o", obj])
 # the host side as well: its experiment switches (environment variables) exist only with -DBN_EXPERIMENTS
 capi = os.path.join(out_dir, f"capi_{name}.o")
 subprocess.check_call([b.hipcc(), *compile_flags, *flags, "-x", "hip", "-c", os.path.join(b.CSRC, "mppi_capi.cpp"), "-o", capi])
-others = [capi] + [os.path.join(base_dir, os.path.splitext(s)[0] + ".o") for s in b.SOURCES if s not in ("rollout_role_philox.hip", "mppi_capi.cpp")]
+others = [capi] + [os.path.join(base_dir, os.path.splitext(s)[0] + ".o") for s in b.SOURCES if s not in (SRC, "mppi_capi.cpp")]
 out = os.path.join(out_dir, f"lib_{name}.so")
 subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", obj, *others, "-o", out])
 print("built", out)

@@ -9,7 +9,7 @@ from benchnav_amd import build as b
 b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ.get("BN_VARIANT", "timing"))
 from benchnav_amd import NativeMPPI, synth
 inst = synth.make_instance(256, seed=0)
-pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, kernel="lat")
+pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, kernel="lat", reference_order=bool(int(os.environ.get("BN_REF", "0"))))
 pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
 stamps = torch.zeros(1024, dtype=torch.int64, device="cuda")
 pl._lib.bn_mppi_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
