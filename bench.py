@@ -450,7 +450,7 @@ def main():
                                   "note": "same workload with BN_FLAG_REFERENCE_ORDER: sincos of every step's heading and x + ((trav v) cos) dt as "
                                           "robot_model.py:86-88 writes it, on the same kernels (rollout_role_ref_*.hip: the chain wave integrates the "
                                           "heading itself); see parity_census for what it buys.  Batched launches and the ticket paths pay 1-8 % for it "
-                                          "(tools/ref_rate.py), this single-instance latency path ~45 %"}
+                                          "(tools/ref_rate.py), this single-instance latency path ~38 %"}
         # Which number is the parity number.  `value` above is measured in the default arithmetic (config.arithmetic), which keeps
         # SURVEY 8a's trajectory tolerance (i) for all but ~3e-5 of rollouts (parity_census: every exception is a counted cell flip);
         # the arithmetic that meets (i) outright is this one, on the same workload, sustained over the same number of dependent solves
