@@ -8,12 +8,14 @@ sys.path.insert(0, ROOT)
 from benchnav_amd import build as b
 args = sys.argv[1:]
 timing = "--timing" in args
-args = [a for a in args if a != "--timing"]
+plain = "--plain" in args          # without -DBN_EXPERIMENTS: the kernels as the shipped library compiles them (that define alone moves the
+                                   # period of dependent solves by 0.8 us, DESIGN_NOTEBOOK.md R5.4); no environment switches then
+args = [a for a in args if a not in ("--timing", "--plain")]
 name, flags = args[0], args[1:]
 SRC = os.environ.get("BN_VARIANT_SRC", "rollout_role_philox.hip")      # the one kernel source compiled with the extra flags
 out_dir = os.path.join(ROOT, "tools", "_ablate")
 os.makedirs(out_dir, exist_ok=True)
-compile_flags = [f for f in b.HIPCC_FLAGS if f != "-shared"] + ["-DBN_EXPERIMENTS"]
+compile_flags = [f for f in b.HIPCC_FLAGS if f != "-shared"] + ([] if plain else ["-DBN_EXPERIMENTS"])
 base_dir = os.path.join(b.LIB_DIR, "obj")
 if timing:
     flags = ["-DBN_TIMING"] + flags
