@@ -356,8 +356,12 @@ def test_fresh_handles_keep_the_last_solves_trajectories():
                     assert np.array_equal(a_, b_), (n, rep, b, j)
 
 
-def test_mixed_call_sequences_and_a_long_chain():
-    """Batches of different lengths, single solves, getters and a changed state in between; then 3000 solves in one call."""
+@pytest.mark.parametrize("reference_order", [False, True], ids=["spec", "reference-order"])
+def test_mixed_call_sequences_and_a_long_chain(reference_order):
+    """Batches of different lengths, single solves, getters and a changed state in between; then 3000 solves in one call.
+    (Round 5: the tails of overlapped solves order only their stores -- default arithmetic -- or stage their window before their rows
+    are there and check the state behind the wait -- reference order: the batches that change the start state are what a stale
+    window would show up in, through X*.)"""
     import torch
     from benchnav_amd import synth
     K, T = 512, 20
@@ -367,19 +371,23 @@ def test_mixed_call_sequences_and_a_long_chain():
     torch.cuda.synchronize()
     res = {}
     for overlap in (False, True):
-        with _make(K, T, 1, [inst], overlap, kernel="lat") as pl:
+        with _make(K, T, 1, [inst], overlap, kernel="lat", reference_order=reference_order) as pl:
             seq = []
             pl.solve_n_async_device(7, st.data_ptr())
             seq.append(pl.get_mean(0))                       # getter: flushes the pending tail
             pl.solve_async_device(st2.data_ptr())            # a single solve between batches (one stream)
             pl.solve_n_async_device(4, st2.data_ptr())
             seq.append(pl.weights(0))
+            seq.extend(_outputs(pl, 1, T)[0])                # (X* of a batch whose slots still hold the other state)
+            pl.solve_n_async_device(40, st.data_ptr())
+            pl.solve_n_async_device(25, st2.data_ptr())      # two long batches back to back, the state changes between them
+            seq.extend(_outputs(pl, 1, T)[0])
             pl.solve_n_async_device(3, st.data_ptr())
             pl.solve_n_async_device(2, st.data_ptr())        # too short to overlap
             seq.append(pl.costs(0))
             pl.solve_n_async_device(3000, st.data_ptr())
             seq.extend(_outputs(pl, 1, T)[0])
-            assert pl.solve_count() == 7 + 1 + 4 + 3 + 2 + 3000
+            assert pl.solve_count() == 7 + 1 + 4 + 40 + 25 + 3 + 2 + 3000
             res[overlap] = seq
     for j, (a_, b_) in enumerate(zip(res[True], res[False])):
         assert np.array_equal(a_, b_), j
