@@ -852,10 +852,11 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     // the waves that write (1 ..) wait for the tail before this one just before their first store, behind the merge; wave 0 rolls U*
     // out into LDS meanwhile and meets them at the barrier in front of its own stores.  (Episodes: the environment step reads what the
     // previous tail wrote -- the wait stays in front.)
-    // (Reference order: its tail -- a sine and a cosine per step of the serial rollout -- is as long as its period either way, and the
-    // build with the deferred wait measured 13.1 us per dependent solve against 11.5 without: left as it was.)
-    const bool defer_tail_wait = AGENT && !REF && NT > 64 && !p.env_on && !p.slip_on && !p.tail_merged;
-    // Reference order, whose tail is as long as its period (the wait for the previous tail stays in front there): while the solve whose
+    // (Reference order: its tail -- a sine and a cosine per step of the serial rollout -- is as long as its period; with the window
+    // staged early, below, the deferred wait brings it from 11.05 to 10.8 us per dependent solve.  Alone it had measured 13.1 against
+    // 11.5: the phase between the successor's polls and the publication, DESIGN_NOTEBOOK.md R5.4.)
+    const bool defer_tail_wait = AGENT && NT > 64 && !p.env_on && !p.slip_on && !p.tail_merged;
+    // Reference order, whose tail is as long as its period: while the solve whose
     // tail this is still runs, the window is staged around the state as it reads NOW -- two dependent fetches that were the first
     // 1.4 us of the tail after the rows: 11.5 -> 10.9 us per dependent solve.  The state is written early in that solve's prologue
     // and almost always there; a thread that read something else (checked below against the load behind the wait) stages its cells

@@ -92,7 +92,7 @@ enum {
                                           T = 100) then lands in a neighbouring cell and leaves the 1e-4 trajectory tolerance from there on
                                           (tests/golden/census_*.npz); with this flag none did in 0.7 M rollouts at T = 50 and
                                           one in 0.7 M at T = 100 -- the level of libm against the reference's own SLEEF.  Every kernel has
-                                          an instantiation in this arithmetic; the price is the chain's extra instructions: 11.0 instead of
+                                          an instantiation in this arithmetic; the price is the chain's extra instructions: 10.8 instead of
                                           8.0 us per dependent single-instance solve, 1-8 % for batched launches and K > 4096 (DESIGN.md
                                           4.15).  dt * max|omega| > 0.5 selects this arithmetic
                                           by itself).  bn_mppi_arithmetic() tells which arithmetic a handle runs. */
