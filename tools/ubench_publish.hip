@@ -29,7 +29,11 @@ __device__ __forceinline__ unsigned long long ld_gran(const unsigned long long *
 // MODE bit 0: burst publication (one wave, 16-byte stores) instead of the scattered pattern; bit 1: only the chain-like wave polls
 // (8 columns + the leading pair) until it has seen them, the other two waves start then; bit 2: pollers sleep ~0.1 us between polls;
 // bit 3: only two of the sixteen waiting workgroups poll; bit 4: waves 2 and 3 poll ONE granule per row (its last column, written in the
-// second pass) plus the leading pair, and read their columns once behind it
+// second pass) plus the leading pair, and read their columns once behind it; bit 5: the pollers poll ANOTHER array that nobody writes
+// (same size, same pattern) and give up 3 us after the publication: is a poll slow because of the stores as such, or because they go to
+// the lines it reads?  bit 6: one SENTINEL per row in a line of its own (256 bytes apart), written behind the row's last store without
+// waiting for anything; wave 1 polls the sixteen sentinels (one load in sixteen lanes), then all three waves read their granules, which
+// validate themselves by their tags (read again until they do).  (`seen` then holds the give-up time; the poll durations printed are the longest of the window and its neighbours)
 template <int MODE>
 __global__ __launch_bounds__(320) void k_pub(unsigned long long *gran, unsigned long long t0, unsigned long long *wlast, unsigned long long *seen,
                                              unsigned long long *polls)
@@ -53,6 +57,7 @@ __global__ __launch_bounds__(320) void k_pub(unsigned long long *gran, unsigned 
                         asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
                     }
                     if (lane == 0) wlast[(size_t)g * kRows + wg] = wall();
+                    if ((MODE & 64) && lane == 0) st_gran(gran + 8192 + 32 * wg, 0.0f, tag);
                 }
             } else {
                 // pass 1: 320 items, item = thread: column j = tid >> 2, lanes with (tid & 3) == 0 store; waves start 0-0.1 us apart
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(320) void k_pub(unsigned long long *gran, unsigned 
                     const int j = (tid + 320) >> 2;
                     if ((tid & 3) == 0 && j < kCols) st_gran(row + 2 + j, 1.0f + j, tag);
                     if (tid == 0) wlast[(size_t)g * kRows + wg] = wall();
+                    if ((MODE & 64) && tid == 0) st_gran(gran + 8192 + 32 * wg, 0.0f, tag);      // the sentinel: behind this wave's last store
                 }
                 if (tid == 192) { while (wall() < tg + 35) { } st_gran(row, 0.5f, tag); st_gran(row + 1, 0.25f, tag); }
             }
@@ -83,6 +89,58 @@ __global__ __launch_bounds__(320) void k_pub(unsigned long long *gran, unsigned 
         if ((MODE & 2) && wid != 1) { while (*(volatile int *)&flag != g + 1) __builtin_amdgcn_s_sleep(1); }
         bool got = false;
         unsigned long long ts = wall(), te = ts, prev = 0, prev2 = 0;
+        if (MODE & 64) {
+            if (wid == 1) {
+                bool all = false;
+                while (!all) {
+                    ts = wall();
+                    const unsigned long long sv = ld_gran(gran + 8192 + 32 * min(lane, kRows - 1));
+                    all = __builtin_amdgcn_ballot_w64((uint32_t)(sv >> 32) != tag) == 0;
+                    if (!all) { prev2 = prev; prev = wall() - ts; }
+                }
+                if (lane == 0) *(volatile int *)&flag = g + 1;
+            } else {
+                while (*(volatile int *)&flag != g + 1) __builtin_amdgcn_s_sleep(1);
+            }
+            while (!got) {
+                ts = wall();
+                unsigned long long v[kRows], mi, si;
+#pragma unroll
+                for (int i = 0; i < kRows; ++i) v[i] = ld_gran(gran + (size_t)i * kPS + 2 + col);
+                mi = ld_gran(gran + (size_t)min(lane, kRows - 1) * kPS);
+                si = ld_gran(gran + (size_t)min(lane, kRows - 1) * kPS + 1);
+                bool ok = (uint32_t)(mi >> 32) == tag && (uint32_t)(si >> 32) == tag;
+#pragma unroll
+                for (int i = 0; i < kRows; ++i) ok = ok && (uint32_t)(v[i] >> 32) == tag;
+                got = __builtin_amdgcn_ballot_w64(!ok) == 0;
+                te = wall();
+            }
+            if (lane == 0) {
+                const size_t o = ((size_t)g * kRows + p_) * 3 + (wid - 1);
+                seen[o] = te; polls[o * 3 + 0] = te - ts; polls[o * 3 + 1] = prev; polls[o * 3 + 2] = prev2;
+            }
+            continue;
+        }
+        if (MODE & 32) {
+            const unsigned long long *other = gran + 4096;   // (32 KB behind the rows: allocated, never written)
+            unsigned long long worst = 0, first = 0;
+            while (wall() < tg + 300) {
+                ts = wall();
+                unsigned long long acc = 0;
+#pragma unroll
+                for (int i = 0; i < kRows; ++i) acc += ld_gran(other + (size_t)i * kPS + 2 + col);
+                acc += ld_gran(other + (size_t)min(lane, kRows - 1) * kPS) + ld_gran(other + (size_t)min(lane, kRows - 1) * kPS + 1);
+                asm volatile("" :: "v"(acc));
+                te = wall();
+                if (ts < tg && first == 0) first = te - ts;
+                if (ts >= tg && ts < tg + 150) worst = max(worst, te - ts);
+            }
+            if (lane == 0) {
+                const size_t o = ((size_t)g * kRows + p_) * 3 + (wid - 1);
+                seen[o] = te; polls[o * 3 + 0] = worst; polls[o * 3 + 1] = first; polls[o * 3 + 2] = 0;
+            }
+            continue;
+        }
         while (!got) {
             ts = wall();
             unsigned long long v[kRows], mi, si;
@@ -118,7 +176,7 @@ template <int MODE>
 static void run(const char *label)
 {
     unsigned long long *gran, *wlast, *seen, *polls;
-    (void)hipMalloc(&gran, kRows * kPS * 8); (void)hipMemset(gran, 0, kRows * kPS * 8);
+    (void)hipMalloc(&gran, 8 * 16384); (void)hipMemset(gran, 0, 8 * 16384);
     (void)hipMalloc(&wlast, kGen * kRows * 8); (void)hipMemset(wlast, 0, kGen * kRows * 8);
     (void)hipMalloc(&seen, kGen * kRows * 3 * 8); (void)hipMalloc(&polls, kGen * kRows * 9 * 8);
     (void)hipFuncSetAttribute((const void *)k_pub<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 81 * 1024);
@@ -159,8 +217,10 @@ int main()
     run<2>("scattered stores; waves 2 and 3 start polling when wave 1 has seen its columns");
     run<4>("scattered stores; ~0.1 us of sleep between polls");
     run<3>("burst + staged polling");
-    run<8>("scattered stores; only two waiting workgroups poll");
-    run<9>("burst; only two waiting workgroups poll");
+    run<64>("scattered stores + one sentinel per row in its own line; wave 1 polls the sentinels, then everybody reads (tags validate)");
+    run<65>("burst + sentinel");
+    run<32>("scattered stores; the pollers read ANOTHER array (first figure: give-up time, meaningless; `saw them` = the longest poll within 1.5 us of the publication, `before` = an idle poll)");
+    run<33>("burst; the pollers read another array");
     run<16>("scattered stores; waves 2 and 3 poll one sentinel per row, then read their columns");
     run<17>("burst; waves 2 and 3 poll one sentinel per row, then read their columns");
     return 0;
