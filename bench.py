@@ -529,6 +529,9 @@ def main():
                                        "roofline": roof(bytes_8, ms_8, f"rollout_{a.noise}_B{B8}", bytes_8w)}
             if "no_overlap" in res_b:
                 out["batched"]["no_overlap"] = res_b["no_overlap"]
+        # ---- the reference's own boundary: MPPI.forward(state) once per control step, host consuming action_seq[0] -------------
+        out["dropin_forward"] = dropin_forward(inst, dev, max(a.steps, 1000))
+        out["value_dropin_forward"] = out["dropin_forward"]["value"]
         # ---- closed loop on the device: solve -> PlanetaryEnv.step -> solve ..., one launch per control step ----
         plc = make_planner(inst)
         plc.env_attach(inst.risk.numpy(), np.full((G, G), 0.05, np.float32))      # latent slip ~ N(risk, 0.05)
@@ -627,6 +630,79 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         emit(out)
+
+
+def dropin_forward(inst, dev, n_steps):
+    """The path a BenchNav user gets after changing the import: `benchnav_amd.MPPI(...)` built from reference-shaped `dynamics` /
+    `objectives` objects and driven as the reference's loop drives it (test/test_mppi.py:174-181) -- one `forward(state)` per control
+    step, the state living on the HOST and changing every step, the host consuming `action_seq[0]` before it can take the next step.
+    Per step: forward() (ONE launch on the latency kernel: rollouts and the solve's own tail, bn_mppi_forward_state_async -- the state
+    travels in the kernel arguments), first_action() (polls the tail's pinned-memory mailbox: no stream synchronisation, no copy), and a
+    host-side environment step (the unicycle transit of planetary_env.py:203-205 on three Python floats with a nearest-cell lookup in the
+    host copy of the risk map).  Also timed: the unmodified reference loop's read-back, `action_seq[0].cpu()`."""
+    import math
+    import types
+    import numpy as np
+    import torch
+    from benchnav_amd import MPPI
+    c = G * RES / 2
+    gm = types.SimpleNamespace(grid_size=G, resolution=RES, x_limits=(c - G / 2 * RES, c + G / 2 * RES), y_limits=(c - G / 2 * RES, c + G / 2 * RES))
+    dyn = types.SimpleNamespace(_grid_map=gm, _traversability_model=types.SimpleNamespace(_risks=inst.risk), _model_config=types.SimpleNamespace(mode="inference"),
+                                min_action=torch.tensor([0.0, -1.0]), max_action=torch.tensor([1.0, 1.0]))
+    obj = types.SimpleNamespace(_goal_pos=inst.goal, _stuck_threshold=0.3, stage_cost=None, terminal_cost=None)
+    solver = MPPI(horizon=T, num_samples=K, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, sigmas=torch.tensor([0.5, 0.5]), lambda_=0.5,
+                  device=torch.device("cuda", dev), seed=42, noise="philox", store_controls=False)
+    risk = inst.risk.numpy()
+    state = inst.start.clone()                           # a CPU tensor, rewritten in place every step (forward() takes it by value)
+    sv = state.numpy()
+    s0 = sv.copy()
+    hi = G * RES
+
+    def env_step(a0, a1):                                # PlanetaryEnv.step's transit (robot_model.py:75-95) on the host, dt = 0.1
+        x, y, th = float(sv[0]), float(sv[1]), float(sv[2])
+        trav = 1.0 - min(max(float(risk[min(max(int(y / RES), 0), G - 1), min(max(int(x / RES), 0), G - 1)]), 0.0), 1.0)
+        sv[0] = min(max(x + trav * a0 * math.cos(th) * 0.1, 0.0), hi)
+        sv[1] = min(max(y + trav * a0 * math.sin(th) * 0.1, 0.0), hi)
+        sv[2] = (th + trav * a1 * 0.1 + math.pi) % (2 * math.pi) - math.pi
+
+    def loop(n, readback):
+        t_f = t_a = t_e = 0.0
+        sv[:] = s0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            if i % 75 == 0:
+                sv[:] = s0                               # episodes of 75 control steps (the goal is ~85 steps away): the rollouts keep their reach
+            ta = time.perf_counter()
+            U, X = solver.forward(state)
+            tb = time.perf_counter()
+            act = U[0].cpu() if readback else solver.first_action()
+            a0, a1 = float(act[0]), float(act[1])
+            tc = time.perf_counter()
+            env_step(a0, a1)
+            td = time.perf_counter()
+            t_f += tb - ta; t_a += tc - tb; t_e += td - tc
+        wall = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return wall / n, t_f / n, t_a / n, t_e / n
+
+    loop(200, False)
+    best = min((loop(n_steps, False) for _ in range(3)), key=lambda r: r[0])
+    rb = min((loop(max(n_steps // 2, 300), True) for _ in range(2)), key=lambda r: r[0])
+    lpf = int(solver._lib.bn_mppi_launches_per_forward(solver._handle))
+    # cross-check of what the loop consumed: the mailbox value IS action_seq[0]
+    U, X = solver.forward(state)
+    same = bool(torch.equal(solver.first_action(), U[0].cpu()))
+    return {"value": 1.0 / best[0], "unit": "control steps/s", "us_per_step": best[0] * 1e6, "steps": n_steps,
+            "split_us": {"forward_call_host": best[1] * 1e6, "first_action_wait": best[2] * 1e6, "host_env_step": best[3] * 1e6,
+                         "loop_overhead": (best[0] - best[1] - best[2] - best[3]) * 1e6},
+            "launches_per_forward": lpf, "first_action_equals_action_seq0": same,
+            "with_cpu_readback": {"value": 1.0 / rb[0], "us_per_step": rb[0] * 1e6,
+                                  "note": "the unmodified reference loop: action_seq[0].cpu() instead of first_action() -- a stream synchronisation and a copy"},
+            "config": {"class": "benchnav_amd.MPPI (drop-in for src/planners/local_planners/mppi.py:MPPI)", "noise": "philox", "copy_outputs": True,
+                       "state": "host (CPU tensor), new every control step", "workload": "BASELINE configs[1]: K=1024, T=50, 256x256"},
+            "note": "one solve per step with the host in the loop: launch latency, the whole solve's latency and the mailbox's trip to the host are "
+                    "paid every step, nothing overlaps -- the reference boundary's figure; `value` above is the device-side chain of dependent solves"}
 
 
 def run_workload(a, which, steps, rank, world, dev, dist, coll_dev, sync, stream, shared_gpu, backend, ndev):

@@ -28,7 +28,7 @@ BN_FLAG_LAT_KERNEL = 1024
 BN_FLAG_NO_OVERLAP = 2048
 BN_FLAG_REFERENCE_ORDER = 4096
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Config(C.Structure):
@@ -60,12 +60,14 @@ SYMBOLS = {
     "bn_mppi_solve": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int, _FP, _FP]),
     "bn_mppi_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_forward_async": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "bn_mppi_forward_state_async": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bn_mppi_solve_n_async": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int64]),
     "bn_mppi_set_rollout_offset": (C.c_int, [_H, C.c_int64]),
     "bn_mppi_shard_rollout_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_shard_partials": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "bn_mppi_shard_finish_async": (C.c_int, [_H, C.c_void_p, C.c_int32]),
     "bn_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "bn_mppi_shard_comm_prepare": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "bn_mppi_shard_comm_init": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
     "bn_mppi_shard_solve_async": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bn_mppi_env_attach": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_uint64]),
@@ -94,6 +96,7 @@ SYMBOLS = {
     "bn_mppi_solve_count": (C.c_uint64, [_H]),
     "bn_mppi_arithmetic": (C.c_int32, [_H]),
     "bn_mppi_launches_per_solve": (C.c_int32, [_H]),
+    "bn_mppi_launches_per_forward": (C.c_int32, [_H]),
     "bn_mppi_fast_quotient": (C.c_int32, [_H]),
     "bn_mppi_row_pitch": (C.c_int32, [_H]),
     "bn_mppi_kernel_ms": (C.c_int, [_H, _FP, _FP, C.POINTER(C.c_int32)]),

@@ -207,11 +207,19 @@ struct bn_mppi {
     bool arm_snap = false;                      // the next launch keeps its mean in d_mean_snap
     bool replaying = false, last_batch_overlapped = false;
     uint64_t journal_solves0 = 0, recoveries = 0;
+    // One launch per SYNCHRONOUS solve (round 6; bn_mppi_forward_async, bn_mppi_forward_state_async, bn_mppi_solve on the latency kernel):
+    // the solve's own tail rides in its launch as a second aux workgroup (SolveParams::self_tail) -- no stand-alone finish kernel.
+    float *self_out_copy = nullptr;  // the caller's U* | X* block of the forward() being enqueued (consumed by solve_impl)
+    const float *inline_state = nullptr;   // host pointer: the state of the forward() being enqueued travels in the kernel arguments
+    bool self_tail_launched = false; // the latest solve_impl call took the one-launch path (its tail is NOT pending)
+    bool self_used = false;          // a self tail's bounded wait could have expired since the error word was last looked at
+    bool self_off = false;           // ... and one did: two launches per synchronous solve from then on
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
     void *shard_comm = nullptr;      // ncclComm_t of bn_mppi_shard_comm_init: the exchange is enqueued by the library on the handle's stream
     int shard_world = 0, shard_rank = 0;
+    bool shard_prepared = false;     // bn_mppi_shard_comm_prepare has run: buffers, events, side stream exist; the communicator may not yet
     bool shard_inplace = false;               // set around the rollouts of bn_mppi_shard_solve_async
     float *d_gathered = nullptr;     // (shard_world x nblk, 2 + 2T): every shard's partial rows, rank order
     float *d_shard_merged = nullptr; // kSlots x [U* (2T) then (max z, sum e)]: what the merge kernel hands to the tail on the side stream
@@ -442,10 +450,30 @@ int sync_checked(bn_mppi *h)
     return settle_overlap(h, true);
 }
 
+// The tail of a one-launch synchronous solve waits (bounded) for the rollout workgroups of its OWN launch.  They are dispatched before
+// it and wait for nobody, so the wait ends -- as surely as a barrier does; should it ever expire (the error word, looked at here for
+// free) the latest solve's outputs are invalid and there is nothing to re-run from: report it, and keep to two launches from then on.
+int self_check(bn_mppi *h)
+{
+    if (!h->self_used || h->overlap_used || h->replaying) return BN_OK;      // (behind overlapped batches: settle_overlap looks at the same word)
+    if (__atomic_load_n(h->h_err, __ATOMIC_ACQUIRE) == 0) return BN_OK;
+    BN_HIP(hipStreamSynchronize(h->stream));
+    BN_HIP(hipMemset(h->d_flags, 0, ((kSlots + 1) * (size_t)h->p.B + 3) * bn::kFlagStride * sizeof(unsigned long long)));
+    for (int q = 0; q < kSlots; ++q) h->pub[q] = 0;
+    h->tails = 0;
+    *h->h_err = 0;
+    h->self_used = false;
+    h->self_off = true;
+    return fail(BN_ERR_HIP, "the tail of a one-launch solve gave up waiting for the rollout workgroups of its own launch: the outputs of solve %llu "
+                            "are invalid (solve again); this handle goes back to two launches per synchronous solve",
+                (unsigned long long)h->solves - 1);
+}
+
 // Entry points that hand results to the host, change the planner's inputs, or enqueue work the journal does not describe: whatever
 // an expired wait could have spoilt is repaired first.  Free unless overlapped launches are outstanding (then: one synchronisation).
 int settle_point(bn_mppi *h)
 {
+    if (int rc = self_check(h)) return rc;
     if (!h->overlap_used || h->replaying) return BN_OK;
     if (int rc = flush_tail(h)) return rc;
     return sync_checked(h);
@@ -829,7 +857,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
         v.erase(std::remove(v.begin(), v.end(), h), v.end());
     }
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    if (h->shard_comm) shard_comm_release(h);
+    if (h->shard_comm || h->shard_prepared) shard_comm_release(h);
     void *bufs[] = {h->d_map, h->d_state, h->d_goal, h->d_mean, h->d_eps, h->d_X, h->d_U, h->d_cost_out,
                     h->d_w, h->d_ustar /* d_xstar lives in the same block */, h->d_stats, h->d_scratch, h->d_idx, h->d_lat_mean, h->d_lat_std,
                     h->d_ep_states, h->d_ep_reward, h->d_env_state, h->d_ep_done, h->d_ep_action, h->d_slip_std,
@@ -1096,6 +1124,29 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             p.wait_tail = h->tails;                                    // ... after every tail (of the same instance) before it
             h->tails += 1;
         }
+        // A synchronous solve on the latency kernel: publishes like a member of a batch (counters, granules) -- for its OWN tail, the second
+        // aux workgroup of the same launch; it waits for nobody (no predecessor in flight, no tail pending: the callers see to that).
+        const bool lone_self = self_tail && !overlap && h->lat_kernel && !h->in_episode && !p.have_prev && !h->replaying && !h->self_off &&
+                               !(h->cfg.flags & BN_FLAG_NO_PIPELINE);
+        h->self_tail_launched = false;
+        if (lone_self) {
+            p.flag_part = h->d_flags;
+            p.err = h->d_err; p.err_dev = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 2) * bn::kFlagStride);
+            p.cur_slot = cur3; p.prev_slot = prev3;
+            p.wait_part = h->pub[prev3];
+            p.gran = h->d_gran[cur3];                                  // (null above 16 workgroups per instance: the tail waits for the counter)
+            p.overlap = 0;
+            h->pub[cur3] += (unsigned long long)p.nblk;
+            p.self_tail = 1;
+            p.wait_part_self = h->pub[cur3];
+            p.wait_tail_self = h->tails;
+            h->tails += 1;
+            p.out_copy_self = h->self_out_copy;
+            if (h->inline_state && p.B == 1) { p.state_inline = 1; std::memcpy(p.sv, h->inline_state, 12); }
+            h->self_used = true;
+            h->self_tail_launched = true;
+            h->prev_published = false;
+        } else
         if ((h->lat_kernel || h->role_overlap) && overlap) {   // member of an overlapped batch: publishes, and waits if its predecessor published
             p.flag_part = h->d_flags;
             p.err = h->d_err; p.err_dev = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 2) * bn::kFlagStride);                                          // pinned host memory, mapped
@@ -1134,6 +1185,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         h->solves += 1;
         h->tail_pending = !p.self_tail;
         if (p.self_tail) h->prev_published = false;                // the next solve starts from the mean that tail writes, in stream order
+        if (lone_self) h->last_batch_overlapped = false;
         return BN_OK;
     }
     if (!(h->ticket_overlap && overlap && !shard_rollout)) h->prev_published = false;
@@ -1214,16 +1266,30 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     return solve_impl(h, states, states_where, eps, noise, false);
 }
 
-int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise, float *out_device)
+// MPPI.forward as ONE call -- and, on the latency kernel, ONE launch: the solve's tail (merge -> U* -> first-action mailbox -> X* ->
+// weights) rides in the rollout launch as a second aux workgroup that waits on the device for the rollout workgroups of its own launch.
+static int forward_impl(bn_mppi_t *h, const float *states_device, const float *state_host, const float *eps_device, bn_noise_kind noise,
+                        float *out_device)
 {
-    // MPPI.forward as ONE call for a host loop that consumes every solve's outputs (test_mppi.py:174-183): the solve and
-    // its tail, both only enqueued; U*, X*, weights are in the device buffers in stream order.
     if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (!states_device && !state_host) return fail(BN_ERR_INVALID, "states is null");
     {
         BN_BIND(h);
         if (int rc = settle_point(h)) return rc;       // behind overlapped batches: those are checked (one synchronisation) first
+        // a tail still pending (an earlier bn_mppi_solve_async): written by its own kernel first -- the one-launch path carries no other
+        // tail than its own (two tails of one launch would write the outputs from two workgroups with different store scopes)
+        if (h->lat_kernel && h->tail_pending && !h->self_off) { if (int rc = flush_tail(h)) return rc; }
     }
-    if (int rc = solve_impl(h, states_device, BN_MEM_DEVICE, eps_device, noise, false)) return rc;
+    h->self_out_copy = out_device;
+    // by value: one instance on the latency kernel travels in the kernel arguments; anything else is staged and uploaded (bn_mppi_solve_async's host path)
+    const bool by_value = state_host && h->p.B == 1 && h->lat_kernel && !h->self_off && !h->tail_pending && !(h->cfg.flags & BN_FLAG_NO_PIPELINE);
+    h->inline_state = by_value ? state_host : nullptr;
+    const float *st = by_value ? h->d_state : (state_host ? state_host : states_device);
+    const int rc0 = solve_impl(h, st, (state_host && !by_value) ? BN_MEM_HOST : BN_MEM_DEVICE, eps_device, noise, false, false, nullptr, 0, true);
+    h->self_out_copy = nullptr;
+    h->inline_state = nullptr;
+    if (rc0) return rc0;
+    if (h->self_tail_launched) return BN_OK;           // tail and the caller's copy ride in the launch
     BN_BIND(h);
     if (!h->tail_pending && out_device) {              // two-launch modes: the tail has run; one small copy on the stream
         const size_t n = (size_t)h->p.B * ((size_t)h->p.T * 2 + ((size_t)h->p.T + 1) * 3);
@@ -1231,6 +1297,20 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
         return BN_OK;
     }
     return flush_tail(h, out_device);
+}
+
+int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise, float *out_device)
+{
+    // MPPI.forward as ONE call for a host loop that consumes every solve's outputs (test_mppi.py:174-183): the solve and
+    // its tail, both only enqueued; U*, X*, weights are in the device buffers in stream order.
+    if (!states_device) return fail(BN_ERR_INVALID, "states is null");
+    return forward_impl(h, states_device, nullptr, eps_device, noise, out_device);
+}
+
+int bn_mppi_forward_state_async(bn_mppi_t *h, const float *states_host, const float *eps_device, bn_noise_kind noise, float *out_device)
+{
+    if (!states_host) return fail(BN_ERR_INVALID, "states is null");
+    return forward_impl(h, nullptr, states_host, eps_device, noise, out_device);
 }
 
 int bn_mppi_set_rollout_offset(bn_mppi_t *h, int64_t first_rollout)
@@ -1319,8 +1399,9 @@ const RcclApi *rccl_api()
 static void shard_comm_release(bn_mppi *h)
 {
     if (h->shard_side) (void)hipStreamSynchronize(h->shard_side);
-    if (const RcclApi *r = rccl_api()) (void)r->comm_destroy(static_cast<ncclComm_t>(h->shard_comm));
+    if (h->shard_comm) { if (const RcclApi *r = rccl_api()) (void)r->comm_destroy(static_cast<ncclComm_t>(h->shard_comm)); }
     h->shard_comm = nullptr;
+    h->shard_prepared = false;
     if (h->d_gathered) (void)hipFree(h->d_gathered);
     if (h->d_shard_merged) (void)hipFree(h->d_shard_merged);
     h->d_gathered = h->d_shard_merged = nullptr;
@@ -1344,40 +1425,59 @@ int bn_dist_unique_id(uint8_t out[BN_DIST_UNIQUE_ID_BYTES])
     return BN_OK;
 }
 
-int bn_mppi_shard_comm_init(bn_mppi_t *h, const uint8_t unique_id[BN_DIST_UNIQUE_ID_BYTES], int32_t world_size, int32_t rank)
+int bn_mppi_shard_comm_prepare(bn_mppi_t *h, int32_t world_size, int32_t rank)
 {
-    if (!h || !unique_id) return fail(BN_ERR_INVALID, "null argument");
+    // Everything bn_mppi_shard_comm_init can fail on BEFORE it enters the collective (ncclCommInitRank): opening RCCL, the handle's
+    // state, the buffers, events and the side stream.  Local, no communication: the ranks of a job call it, agree on the outcome by
+    // whatever means they have (benchnav_amd.sharding: one all-reduce over the torch group), and enter the collective only if every
+    // rank is ready -- a rank that cannot must not leave the others waiting in ncclCommInitRank's bootstrap.
+    if (!h) return fail(BN_ERR_INVALID, "null argument");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(BN_ERR_INVALID, "rank %d outside a world of %d", rank, world_size);
     if (h->p.B != 1 || h->p.slip_on) return fail(BN_ERR_INVALID, "a K-sharded solve takes one instance per handle, without sampled slip");
     if (h->shard_comm) return fail(BN_ERR_STATE, "the handle has a communicator already");
+    if ((size_t)world_size * h->p.nblk > 1024) return fail(BN_ERR_INVALID, "the library's exchange merges at most 1024 workgroups (65536 rollouts)");
+    if (h->shard_prepared) {
+        if (h->shard_world == world_size && h->shard_rank == rank) return BN_OK;
+        return fail(BN_ERR_STATE, "the handle was prepared as rank %d of %d", h->shard_rank, h->shard_world);
+    }
     const RcclApi *r = rccl_api();
     if (!r) return fail(BN_ERR_HIP, "librccl.so could not be opened: %s", dlerror());
     BN_BIND(h);
     if (int rc = settle_point(h)) return rc;
-    ncclUniqueId id;
-    std::memcpy(&id, unique_id, sizeof(id));
-    ncclComm_t comm = nullptr;
-    const ncclResult_t e = r->comm_init_rank(&comm, world_size, id, rank);      // collective: every rank of the solve calls it
-    if (e != ncclSuccess) return fail(BN_ERR_HIP, "ncclCommInitRank: %s", r->error_string(e));
     const size_t bytes = (size_t)world_size * h->p.nblk * (2 + 2 * (size_t)h->p.T) * sizeof(float);
     if (hipMalloc((void **)&h->d_gathered, bytes) != hipSuccess) {
-        (void)r->comm_destroy(comm);
+        (void)hipGetLastError();
+        h->d_gathered = nullptr;
         return fail(BN_ERR_HIP, "hipMalloc of %zu B for the gathered partials failed", bytes);
     }
-    h->shard_comm = comm;
     h->shard_world = world_size;
     h->shard_rank = rank;
     // the side stream of the tail: the handle's second stream if it has one (overlapped batches), else one of its own
     // [ kSlots merged rows | 64 group rows | ticket ]
     const size_t merged_floats = kSlots * (2 * (size_t)h->p.T + 2) + 64 * (2 + 2 * (size_t)h->p.T) + 4;
-    if ((size_t)world_size * h->p.nblk > 1024) { shard_comm_release(h); return fail(BN_ERR_INVALID, "the library's exchange merges at most 1024 workgroups (65536 rollouts)"); }
     bool ok = hipMalloc((void **)&h->d_shard_merged, merged_floats * sizeof(float)) == hipSuccess &&
               hipMemset(h->d_shard_merged, 0, merged_floats * sizeof(float)) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_shard_merge, hipEventDisableTiming) == hipSuccess;
     for (int q = 0; ok && q < kSlots; ++q) ok = hipEventCreateWithFlags(&h->ev_shard_tail[q], hipEventDisableTiming) == hipSuccess;
     if (ok && h->n_streams > 1 && h->xstream[0]) h->shard_side = h->xstream[0];
     else if (ok) { ok = hipStreamCreateWithFlags(&h->shard_side, hipStreamNonBlocking) == hipSuccess; h->shard_side_own = ok; }
-    if (!ok) { shard_comm_release(h); return fail(BN_ERR_HIP, "stream / event / buffer creation for the sharded solve failed"); }
+    if (!ok) { (void)hipGetLastError(); shard_comm_release(h); return fail(BN_ERR_HIP, "stream / event / buffer creation for the sharded solve failed"); }
+    h->shard_prepared = true;
+    return BN_OK;
+}
+
+int bn_mppi_shard_comm_init(bn_mppi_t *h, const uint8_t unique_id[BN_DIST_UNIQUE_ID_BYTES], int32_t world_size, int32_t rank)
+{
+    if (!h || !unique_id) return fail(BN_ERR_INVALID, "null argument");
+    if (int rc = bn_mppi_shard_comm_prepare(h, world_size, rank)) return rc;      // (a no-op behind the caller's own prepare)
+    const RcclApi *r = rccl_api();
+    BN_BIND(h);
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t e = r->comm_init_rank(&comm, world_size, id, rank);      // collective: every rank of the solve calls it
+    if (e != ncclSuccess) { shard_comm_release(h); return fail(BN_ERR_HIP, "ncclCommInitRank: %s", r->error_string(e)); }
+    h->shard_comm = comm;
     return BN_OK;
 }
 
@@ -1387,6 +1487,20 @@ int bn_mppi_shard_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind sta
     if (!h->shard_comm) return fail(BN_ERR_STATE, "bn_mppi_shard_comm_init must precede bn_mppi_shard_solve_async");
     // The rollouts of THIS solve do not wait for the previous solve's tail on the side stream (flush_tail would join it): they read
     // the mean the merge wrote, on this stream.  And they write their partial rows where the all-gather wants them (in place).
+    // Every per-solve buffer rotates over kSlots solves -- the costs and the start state the rollouts below write, the merged row -- and
+    // the side-stream tail of the solve kSlots back still reads its slot (weights, cost copy, X*).  That tail is done unless something is
+    // badly stuck, so the host LOOKS (hipEventQuery) and only a tail still running puts a cross-queue wait in front of the ROLLOUTS
+    // (the check used to sit behind them and covered the merged row only) -- an event wait between queues costs
+    // microseconds on the handle's stream even when the event has long fired (first cut of this path: 72 us per solve with an
+    // unconditional wait against 47 without the split).
+    {
+        BN_BIND(h);
+        const int next = (int)(h->solves % kSlots);
+        if (h->solves >= (uint64_t)kSlots && h->ev_shard_tail[next] && hipEventQuery(h->ev_shard_tail[next]) != hipSuccess) {
+            (void)hipGetLastError();
+            BN_HIP(hipStreamWaitEvent(h->stream, h->ev_shard_tail[next], 0));
+        }
+    }
     const bool inflight = h->shard_tail_inflight;
     h->shard_tail_inflight = false;
     h->shard_inplace = true;
@@ -1400,14 +1514,15 @@ int bn_mppi_shard_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind sta
     const RcclApi *r = rccl_api();
     const ncclResult_t e = r->all_gather(h->d_gathered + (size_t)h->shard_rank * count, h->d_gathered, count, ncclFloat,
                                          static_cast<ncclComm_t>(h->shard_comm), h->stream);
-    if (e != ncclSuccess) return fail(BN_ERR_HIP, "ncclAllGather: %s", r->error_string(e));
+    if (e != ncclSuccess) {
+        h->shard_pending = false;                            // the solve is lost, the handle is not: the next call starts a new one
+        return fail(BN_ERR_HIP, "ncclAllGather: %s", r->error_string(e));
+    }
     // Merge on the handle's stream -- U*, the next mean, the softmin statistics: all the next solve's rollouts wait for -- and the
     // rest of the tail (X* rollout, the shard's weights, the cost copy: ~10 us of one workgroup) on the side stream, beside them.
-    // What the two streams share: the outputs (tails stay in order on their one stream), the per-solve slots of costs / states, and
-    // the merged row (written by the merge, read by the tail) -- all rotating over kSlots solves.  A merge reuses the slot of the tail
-    // four solves back: that tail is done unless something is badly stuck, so the host LOOKS (hipEventQuery) and only a tail still
-    // running puts a cross-queue wait in front of the merge -- an event wait between queues costs microseconds on the handle's
-    // stream even when the event has long fired (first cut of this path: 72 us per solve with the wait against 47 without the split).
+    // What the two streams share: the outputs (tails stay in order on their one stream; U* is the merge's alone), the per-solve slots
+    // of costs / states, and the merged row (written by the merge, read by the tail) -- all rotating over kSlots solves and covered by
+    // the look at the tail kSlots back in front of the rollouts, above.
     if (int rc = settle_point(h)) return rc;
     bn::SolveParams p = h->p;
     p.solve = p.tail_solve = h->solves - 1;
@@ -1416,15 +1531,12 @@ int bn_mppi_shard_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind sta
     p.cost = h->d_cost[cur]; p.state = h->d_state_copy[cur];
     float *merged = h->d_shard_merged + (size_t)cur * (2 * (size_t)p.T + 2);
     p.ustar_cur = merged; p.stats_cur = merged + 2 * (size_t)p.T;
-    if (h->solves > (uint64_t)kSlots && hipEventQuery(h->ev_shard_tail[cur]) != hipSuccess) {
-        (void)hipGetLastError();
-        BN_HIP(hipStreamWaitEvent(h->stream, h->ev_shard_tail[cur], 0));
-    }
     float *group_rows = h->d_shard_merged + kSlots * (2 * (size_t)p.T + 2);
     BN_HIP(bn::launch_shard_merge(p, group_rows, reinterpret_cast<int *>(group_rows + 64 * (2 + 2 * (size_t)p.T)), h->stream));
     BN_HIP(hipEventRecord(h->ev_shard_merge, h->stream));
     BN_HIP(hipStreamWaitEvent(h->shard_side, h->ev_shard_merge, 0));
     p.tail_merged = 1;
+    p.ustar_written = 1;                                     // (the merge kernel above wrote U*: see SolveParams::ustar_written)
     p.ustar_prev = merged; p.stats_prev = merged + 2 * (size_t)p.T;
     BN_HIP(bn::launch_finish(p, h->shard_side));            // weights of the local rollouts, normalised by the global sum; X*
     BN_HIP(hipEventRecord(h->ev_shard_tail[cur], h->shard_side));
@@ -1838,7 +1950,8 @@ int bn_mppi_sync(bn_mppi_t *h)
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
     if (int rc = flush_tail(h)) return rc;
-    return sync_checked(h);            // a bounded device-side wait of an overlapped launch may have expired: see recover_overlap
+    if (int rc = sync_checked(h)) return rc;            // a bounded device-side wait of an overlapped launch may have expired: see recover_overlap
+    return self_check(h);
 }
 
 uint64_t bn_mppi_recovery_count(const bn_mppi_t *h) { return h ? h->recoveries : 0; }
@@ -1870,6 +1983,7 @@ int bn_mppi_first_action(bn_mppi_t *h, int32_t instance, float action_host[2])
             if (q != hipSuccess && q != hipErrorNotReady) return fail(BN_ERR_HIP, "the stream failed while waiting for the first action");
         }
     }
+    if (int rc = self_check(h)) return rc;                  // (a one-launch solve: its tail's wait ended before it posted)
     if (h->overlap_used && __atomic_load_n(h->h_err, __ATOMIC_ACQUIRE)) {   // an expired wait upstream: repair, then read the repaired value
         if (int rc = settle_point(h)) return rc;
         const unsigned long long a = m[0], b = m[1];
@@ -1920,14 +2034,15 @@ int bn_mppi_solve(bn_mppi_t *h, const float *states, bn_mem_kind states_where, c
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
     if (int rc = settle_point(h)) return rc;
-    if (int rc = bn_mppi_solve_async(h, states, states_where, eps, noise)) return rc;
+    if (h->lat_kernel && h->tail_pending && !h->self_off) { if (int rc = flush_tail(h)) return rc; }      // (as in forward_impl)
+    if (int rc = solve_impl(h, states, states_where, eps, noise, false, false, nullptr, 0, true)) return rc;   // own tail in the launch where that exists
     if (int rc = flush_tail(h)) return rc;
     const size_t B = h->p.B, T = h->p.T;
     if (ustar_host) BN_HIP(hipMemcpyAsync(ustar_host, h->d_ustar, B * T * 2 * 4, hipMemcpyDeviceToHost, h->stream));
     if (xstar_host)
         BN_HIP(hipMemcpyAsync(xstar_host, h->d_xstar, B * (T + 1) * 3 * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
-    return BN_OK;
+    return self_check(h);
 }
 
 // Rows of the latest solve's trajectory batch, regenerated (launch_reroll).  The tail of that solve must have run
@@ -2107,6 +2222,10 @@ uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves : 0; }
 int32_t bn_mppi_arithmetic(const bn_mppi_t *h) { return h ? h->p.ref_order : -1; }
 int32_t bn_mppi_fast_quotient(const bn_mppi_t *h) { return h ? (h->p.pow2 ? 2 : h->p.fast_div) : -1; }
 int32_t bn_mppi_launches_per_solve(const bn_mppi_t *h) { return h ? ((h->pipelined || h->ticket_mode) ? 1 : 2) : -1; }
+int32_t bn_mppi_launches_per_forward(const bn_mppi_t *h)
+{
+    return h ? ((h->lat_kernel && h->pipelined && !h->self_off && !(h->cfg.flags & BN_FLAG_NO_PIPELINE)) ? 1 : 2) : -1;
+}
 
 int32_t bn_mppi_row_pitch(const bn_mppi_t *h) { return h ? h->p.Kp : 0; }
 

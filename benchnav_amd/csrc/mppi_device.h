@@ -29,6 +29,7 @@ constexpr int TU = kChunk;   // time steps per phase (chunk): chain works on chu
 #define BN_TRACE_BEGIN() do { } while (0)
 #define BN_TRACE_END() do { } while (0)
 #define BN_TIMING_DO(...)
+#define BN_SSTAMP(i) do { } while (0)
 #endif
 
 // Geometry specialisations of the cell index ((p - origin) / res).floor().int()  (grid_map.py:195-209):
@@ -841,10 +842,18 @@ __device__ __forceinline__ void merge_partials(const float *__restrict__ part, i
 // device-scope loads, and write EVERY output with device-scope (sc1, write-through) stores: the tails of consecutive solves run in
 // different kernels, possibly on different XCDs, and write the same addresses -- the tail counter orders the stores themselves, but
 // a plain store may sit dirty in its XCD's L2 until its kernel ends, and which kernel ends last is not ordered by anything.
-template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false, bool WIDE = false, bool REF = false>
+// SELF (round 6): the tail of the solve whose rollouts run in THIS launch (SolveParams::self_tail) -- a synchronous forward() as one
+// launch, or the last launch of a batch.  Nothing it needs before the rows is unknown: the state is the caller's (or travels in the kernel
+// arguments), so the window is staged and in LDS long before the rollout workgroups are through.  With `gran_self` (the granule copies of
+// this solve's partial rows, K <= 1024) every thread then polls the granules IT merges -- one memory round trip from "stored" to "merged",
+// no counter, no second fetch -- and thread 0 posts U*[0] to the host's mailbox the moment the merge is done.  The costs travel as plain
+// device-scope stores, not as granules: the waves that turn them into weights wait for the workgroups' counts (publish_counter: every
+// store acknowledged) first, off the critical path.  Without granules: the counter, then the rows (as AGENT).
+template <int GEO, bool LDSWIN, int NT, bool BIG = false, bool AGENT = false, bool WIDE = false, bool REF = false, bool SELF = false>
 __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const float *part_all, const float *cost_all,
-                                            const float *state_all, float *smem)
+                                            const float *state_all, float *smem, const unsigned long long *gran_self = nullptr)
 {
+    static_assert(!SELF || AGENT, "the tail of a launch's own solve reads what the rollout workgroups of that launch publish");
     // Tails of consecutive overlapped solves write the same output buffers, so they are ordered by a counter.  What has to be ordered are
     // the STORES: with the wait in front of everything (rounds 3-4) a tail started when its predecessor was through, and at ~8.5 us a
     // tail (two dependent fetches, the merge, the 50-step rollout of U*) the chain of tails, not the rollouts, set the period of a batch
@@ -864,14 +873,15 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     // lines there -- even as dead code that only moved declarations -- measured 7.93 -> 8.11 us.)
     float sx0 = 0.0f, sy0 = 0.0f;
     bool staged = false;
-    if constexpr (AGENT && REF && LDSWIN) {
+    if constexpr (AGENT && REF && LDSWIN && !SELF) {
         if (!p.slip_on && !p.env_on) {
             sx0 = ld<AGENT>(state_all + b * 3 + 0); sy0 = ld<AGENT>(state_all + b * 3 + 1);
             stage_window(smem, p.map + (size_t)b * p.map_stride, window_origin<GEO>(p, sx0, sy0), p.WN, p.G, (int)threadIdx.x, NT);
             staged = true;
         }
     }
-    if (AGENT) {
+    const bool self_gran = SELF && gran_self != nullptr && !p.tail_merged;
+    if (AGENT && !SELF) {
         if (threadIdx.x == 0) {
             wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p);   // the solve whose tail this is has published everything
             if (!defer_tail_wait) wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);   // and the tail before it has left the output buffers
@@ -890,27 +900,61 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     const int tid = threadIdx.x;
     const float *__restrict__ map = p.map + (size_t)b * p.map_stride;
     const float *part = part_all + (size_t)b * nblk * PS;
-    const float sx = ld<AGENT>(state_all + b * 3 + 0), sy = ld<AGENT>(state_all + b * 3 + 1), sth = ld<AGENT>(state_all + b * 3 + 2);
+    float sx, sy, sth;
+    BN_SSTAMP(0);
+    if constexpr (SELF) {                              // the state this launch's rollouts start from: the caller's, known from the start
+        if (p.state_inline) { sx = p.sv[0]; sy = p.sv[1]; sth = p.sv[2]; }
+        else { sx = p.state[b * 3 + 0]; sy = p.state[b * 3 + 1]; sth = p.state[b * 3 + 2]; }
+    } else {
+        sx = ld<AGENT>(state_all + b * 3 + 0); sy = ld<AGENT>(state_all + b * 3 + 1); sth = ld<AGENT>(state_all + b * 3 + 2);
+    }
     BN_STAMP(8);
 
     // the merge's loads go out before the window staging (which waits for the state): one memory round trip for both
     MergeLoads pre{};
     const bool pre_ok = !p.tail_merged && nblk <= 64;
-    if (pre_ok) pre = merge_issue<AGENT>(part, nblk, T, tid);
+    if (pre_ok && !SELF) pre = merge_issue<AGENT>(part, nblk, T, tid);
     Win w{0, 0, 0.f, 0.f, 0.f, 0.f};
     if (LDSWIN && !p.slip_on) {
         w = window_origin<GEO>(p, sx, sy);
-        if constexpr (AGENT && REF) { if (!(staged && sx == sx0 && sy == sy0)) stage_window(win, map, w, p.WN, p.G, tid, NT); }   // (per thread: no barrier inside)
+        if constexpr (AGENT && REF && !SELF) { if (!(staged && sx == sx0 && sy == sy0)) stage_window(win, map, w, p.WN, p.G, tid, NT); }   // (per thread: no barrier inside)
         else stage_window(win, map, w, p.WN, p.G, tid, NT);
     }
+    BN_SSTAMP(1);
+    if constexpr (SELF) {
+        // ... and only now the wait for this launch's own rollout workgroups: they were dispatched before this workgroup (grid order) and
+        // wait for nobody that comes after them, so the wait ends; it is bounded all the same (the error word, see bn_mppi_forward_async)
+        if (self_gran) {
+            const unsigned long long *grows = gran_self + (size_t)b * nblk * PS;
+            const uint32_t tag = (uint32_t)p.tail_solve + 1u;
+            bool ok = false;
+            for (int it = 0; it < (1 << 22) && !ok; ++it) {
+                pre = merge_issue_granules(grows, nblk, T, tid, tag, ok, tid);
+                if (!ok) __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) raise_wait_expired(p, nullptr, 901);
+        } else {
+            if (tid == 0) wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p);
+            __syncthreads();
+            if (pre_ok) pre = merge_issue<AGENT>(part, nblk, T, tid);
+        }
+        if (!defer_tail_wait) {                        // (not reached by today's callers: the latency kernel's self tail always defers)
+            if (tid == 0) {
+                if (self_gran) wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p);
+                wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);
+            }
+            __syncthreads();
+        }
+    }
     BN_STAMP(9);
+    BN_SSTAMP(2);
 
     float m, S;
     if (p.tail_merged) {
         for (int j = tid; j < 2 * T; j += NT) {
             const float u = ld<AGENT>(p.ustar_prev + (size_t)b * 2 * T + j);
             us[j] = u;
-            st<AGENT>(p.ustar + (size_t)b * 2 * T + j, u);
+            if (!p.ustar_written) st<AGENT>(p.ustar + (size_t)b * 2 * T + j, u);
             if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, u);
         }
         m = ld<AGENT>(p.stats_prev + b * 2 + 0);
@@ -919,6 +963,14 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     } else {
         merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
     }
+    // No tail in front of this one (a synchronous forward(): every earlier tail was ordered before the launch by the stream): the first
+    // control goes to the host's mailbox at once -- before the wait for the costs, the X* rollout and the weights.
+    const bool mail_early = SELF && !p.have_prev && p.mail != nullptr;
+    if (mail_early && tid == 0) {
+        store_granule_host(p.mail + 2 * b, us[0], (uint32_t)p.tail_solve + 1u);
+        store_granule_host(p.mail + 2 * b + 1, us[1], (uint32_t)p.tail_solve + 1u);
+    }
+    BN_SSTAMP(3);
     // U*, the next mean, the statistics: threads j0, j0 + step, .. (all of them, or -- deferred wait -- the writing waves behind their wait)
     auto store_ustar = [&](int j0, int step, bool first) {
         if (!p.tail_merged) {
@@ -932,7 +984,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             }
         }
         if (first) {
-            if (p.mail) {                              // the first control of U*, for the host that waits for it: out before anything else
+            if (p.mail && !mail_early) {               // the first control of U*, for the host that waits for it: out before anything else
                 store_granule_host(p.mail + 2 * b, us[0], (uint32_t)p.tail_solve + 1u);
                 store_granule_host(p.mail + 2 * b + 1, us[1], (uint32_t)p.tail_solve + 1u);
             }
@@ -1095,7 +1147,12 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         BN_STAMP(11);
     } else if (NT > 64 && tid >= 64) {
         if (defer_tail_wait) {                         // every writing wave waits for itself: wave 0 is on the serial rollout, no barrier to meet at
-            if ((tid & 63) == 0) wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);
+            if ((tid & 63) == 0) {
+                // (granule-polling self tail: the rows are here, the per-rollout costs -- plain device-scope stores -- only once every
+                // rollout workgroup has counted itself in behind its acknowledged stores)
+                if (self_gran) wait_counter(flag_ctr(p.flag_part, p.prev_slot * p.B + b), p.wait_part, p);
+                wait_counter(flag_ctr(p.flag_tail, b), p.wait_tail, p);
+            }
             store_ustar(tid - 64, NT - 64, tid == 64);
         }
         // _weights = softmax(-costs / lambda)   mppi.py:193
@@ -1119,7 +1176,9 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         }
     }
     // optimal_state_seq out of LDS: coalesced, and to the caller's copy of the packed U* | X* block as well
+    BN_SSTAMP(4);
     __syncthreads();
+    BN_SSTAMP(5);
     {
         float *Xg = p.xstar + (size_t)b * (T + 1) * 3;
         float *Xc = p.out_copy ? p.out_copy + (size_t)p.B * 2 * T + (size_t)b * (T + 1) * 3 : nullptr;
@@ -1131,6 +1190,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     }
     // one more tail done (counted per instance): what an overlapped successor's tail waits for before it takes the output buffers
     if (p.flag_tail) publish_counter(flag_ctr(p.flag_tail, b), tid);
+    BN_SSTAMP(6);
 }
 
 // Ticket merge: every workgroup of instance b publishes its partials, takes a ticket, and the one that draws the

@@ -102,6 +102,8 @@ struct SolveParams {
     float *ustar_cur, *stats_cur;      // (B, T, 2), (B, 2): merge outputs of this solve (double-buffered by solve parity)
     const float *ustar_prev, *stats_prev;   // merge outputs of the solve whose tail this launch / the stand-alone tail writes
     int tail_merged;                   // the tail reads (ustar_prev, stats_prev) instead of merging `part`
+    int ustar_written;                 // ... and U* itself is in `ustar` already (the K-sharded solve's merge kernel wrote it on the handle's stream:
+                                       // a tail on the side stream must not write it again behind the NEXT solve's merge)
     uint64_t tail_solve;               // index of the solve whose tail is written (its X* draws)
     // ---- overlapped launches (solve_n_overlapped in mppi_capi.cpp): consecutive solves alternate between two streams, so a launch
     // may start while its predecessor still runs; what stream order used to guarantee is carried by monotonic device counters ----
@@ -128,6 +130,10 @@ struct SolveParams {
                                 // done -- before the X* rollout and the weights -- for a host that consumes every solve (bn_mppi_first_action)
     float *out_copy;     // optional caller-owned copy of the packed (B,T,2) U* | (B,T+1,3) X* block, written by the same tail
                          // (bn_mppi_forward_async: the drop-in class's fresh output tensors without a second launch)
+    float *out_copy_self;   // ... the same for the tail of THIS launch's solve (self_tail): the aux workgroup of the previous solve's tail
+                            // in the same launch must not write the caller's block
+    int state_inline;    // the (one) instance's state travels in the kernel arguments (sv): a host loop that hands over a fresh state
+    float sv[3];         // every control step (bn_mppi_forward_state_async) pays neither an upload nor the prologue's fetch of it
     float *stats;        // (B, 2): max z, sum exp
     int trace_by_parity;          // timing builds: per-workgroup trace rows of odd solves behind those of even solves (two launches in flight)
     unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0

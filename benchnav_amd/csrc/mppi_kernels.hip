@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kShardMergeThreads) void shard_merge_kernel(const S
     }
     for (int j = tid; j < 2 * T; j += kShardMergeThreads) {
         p.ustar_cur[j] = us[j];
-        p.ustar[j] = us[j];                             // (the tail writes the same values again: U* is on the handle's stream from here on)
+        p.ustar[j] = us[j];                             // U* is on the handle's stream from here on (the side-stream tail leaves it alone: ustar_written)
         if (p.mean_used) p.mean_used[j] = p.mean[j];    // what this solve sampled around
         p.mean[j] = us[j];                              // _previous_action_seq = U*, no shift (mppi.py:217)
     }

@@ -40,7 +40,7 @@ __device__ __forceinline__ void park_store4(int idx, float a, float b, float c, 
                  "v_mov_b32 " BN_PARK_REG(2) ", %2\n\t"
                  "v_mov_b32 " BN_PARK_REG(3) ", %3\n\t"
                  "s_set_gpr_idx_off"
-                 : : "v"(a), "v"(b), "v"(c), "v"(d), "s"(idx) : BN_PARK_CLOBBERS);
+                 : : "v"(a), "v"(b), "v"(c), "v"(d), "s"(idx) : BN_PARK_CLOBBERS, "m0");   /* s_set_gpr_idx_on writes M0 (index and mode bits): whoever uses M0 next must set it up again */
 }
 
 // ... and back (volatile: ordered behind the stores)
@@ -52,7 +52,7 @@ __device__ __forceinline__ void park_load4(int idx, float u[4])
                  "v_mov_b32 %2, " BN_PARK_REG(2) "\n\t"
                  "v_mov_b32 %3, " BN_PARK_REG(3) "\n\t"
                  "s_set_gpr_idx_off"
-                 : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]) : "s"(idx));
+                 : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]) : "s"(idx) : "m0");
 }
 
 }  // namespace

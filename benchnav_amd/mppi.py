@@ -200,6 +200,7 @@ class MPPI(nn.Module):
         self._buf_xstar = self._buf_out[T * 2:].view(1, T + 1, 3)
         self._n_out = T * 2 + (T + 1) * 3
         self._fwd = lib.bn_mppi_forward_async                   # bound once: forward() is a host hot loop
+        self._fwd_state = lib.bn_mppi_forward_state_async       # ... for a state that lives on the host (test_mppi.py:174-181)
         self._h = self._handle.value
 
         self._buf_mean = self._wrap(_capi.BN_BUF_MEAN, (T, 2))
@@ -320,7 +321,13 @@ class MPPI(nn.Module):
         if not torch.is_tensor(state):
             state = torch.tensor(state, dtype=self._dtype)
         assert state.shape == (self._dim_state,)
-        if state.device != self._device or state.dtype != self._dtype or not state.is_contiguous():
+        fwd = self._fwd
+        if state.device.type == "cpu":
+            # a host loop's state (the reference moves it, mppi.py:140-144): taken by value at the call -- no upload, no device tensor
+            if state.dtype != self._dtype or not state.is_contiguous():
+                state = state.detach().to(self._dtype).contiguous()
+            fwd = self._fwd_state
+        elif state.device != self._device or state.dtype != self._dtype or not state.is_contiguous():
             state = state.detach().to(self._device, self._dtype).contiguous()
         mode = self._noise_mode
         if mode == "philox":
@@ -339,10 +346,10 @@ class MPPI(nn.Module):
         out = torch.empty(self._n_out, device=self._device, dtype=self._dtype) if self._copy_outputs else None
         optr = None if out is None else out.data_ptr()
         if torch.cuda.current_stream(self._device).cuda_stream == self._stream.cuda_stream:
-            rc = self._fwd(self._h, state.data_ptr(), eptr, kind, optr)   # solve + tail: U*, X*, weights of THIS solve, stream-ordered
+            rc = fwd(self._h, state.data_ptr(), eptr, kind, optr)   # solve + tail: U*, X*, weights of THIS solve, stream-ordered
         else:
             with self._on_planner_stream():
-                rc = self._fwd(self._h, state.data_ptr(), eptr, kind, optr)
+                rc = fwd(self._h, state.data_ptr(), eptr, kind, optr)
         if rc:
             _capi.check(rc)
         if out is not None:

@@ -150,6 +150,18 @@ class NativeMPPI:
         _capi.check(self._lib.bn_mppi_solve_async(self._h, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
                                                   C.c_void_p(eps_ptr), kind))
 
+    def forward_async_device(self, state_ptr: int, eps_ptr: Optional[int] = None, kind: int = _capi.BN_NOISE_PHILOX, out_ptr: Optional[int] = None):
+        """MPPI.forward as one call: solve + tail enqueued (ONE launch on the latency kernel, launches_per_forward())."""
+        _capi.check(self._lib.bn_mppi_forward_async(self._h, C.c_void_p(state_ptr), C.c_void_p(eps_ptr), kind, C.c_void_p(out_ptr)))
+
+    def forward_state_async(self, states, eps_ptr: Optional[int] = None, kind: int = _capi.BN_NOISE_PHILOX, out_ptr: Optional[int] = None):
+        """... with the (B,3) states taken from the host by value at the call (no upload is enqueued for one instance on the latency kernel)."""
+        st = _f32(states).reshape(self.B, 3)
+        _capi.check(self._lib.bn_mppi_forward_state_async(self._h, C.c_void_p(st.ctypes.data), C.c_void_p(eps_ptr), kind, C.c_void_p(out_ptr)))
+
+    def launches_per_forward(self) -> int:
+        return int(self._lib.bn_mppi_launches_per_forward(self._h))
+
     def solve_n_async_device(self, n: int, state_ptr: int, eps_ptr: Optional[int] = None,
                              kind: int = _capi.BN_NOISE_PHILOX, eps_ring: int = 1, eps_stride: int = 0):
         """Enqueue n dependent (warm-started) solves from one C call: no per-launch Python overhead."""
@@ -164,6 +176,10 @@ class NativeMPPI:
     def shard_rollout_async_device(self, state_ptr: int, eps_ptr: Optional[int] = None, kind: int = _capi.BN_NOISE_PHILOX):
         _capi.check(self._lib.bn_mppi_shard_rollout_async(self._h, C.c_void_p(state_ptr), _capi.BN_MEM_DEVICE,
                                                           C.c_void_p(eps_ptr), kind))
+
+    def shard_comm_prepare(self, world_size: int, rank: int):
+        """The local half of shard_comm_init (RCCL opened, buffers, events, side stream): no communication, may fail on one rank only."""
+        _capi.check(self._lib.bn_mppi_shard_comm_prepare(self._h, world_size, rank))
 
     def shard_comm_init(self, unique_id: bytes, world_size: int, rank: int):
         """Collective: the ranks of a K-sharded solve build the RCCL communicator the library enqueues its exchange on."""

@@ -141,23 +141,34 @@ class ShardedMPPI:
         # here: 60 us per solve on one rank).  The communicator's id travels over the group the job has anyway.
         self._fused = False
         if self._direct and self._dist is not None and os.environ.get("BN_SHARD_TORCH_COLLECTIVE") != "1":
-            # ... and every rank must end up on the same path: whoever fails (no librccl to open, communicator refused) makes all of them
-            # keep torch's collective -- agreed with one all-reduce, so that no rank waits in a collective the others never enter
+            # ... and every rank must end up on the same path, and none may wait in a collective the others never enter.  The
+            # communicator's init (ncclCommInitRank) IS a collective: it blocks until every rank has entered.  So everything a rank can
+            # fail on alone -- opening librccl, the handle's state, the exchange buffers, rank 0 drawing the id -- happens first and
+            # locally (shard_comm_prepare), the ranks agree on the outcome with one all-reduce over the torch group, and only a
+            # unanimous "ready" takes them into the collective; its own outcome is agreed the same way.
+            ready, uid = 1, None
             try:
-                box = [unique_id() if self.rank == 0 else None]
+                self.planner.shard_comm_prepare(self.world, self.rank)
+                if self.rank == 0:
+                    uid = unique_id()
             except Exception:
-                box = [None]
-            self._dist.broadcast_object_list(box, src=self._dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ok = 0
-            if box[0] is not None:
+                ready = 0
+            if self._agree(ready, group):
+                box = [uid]
+                self._dist.broadcast_object_list(box, src=self._dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ok = 0
                 try:
                     self.planner.shard_comm_init(box[0], self.world, self.rank)
                     ok = 1
                 except Exception:
                     ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
-            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN, group=group)
-            self._fused = bool(int(flag.item()))
+                self._fused = self._agree(ok, group)
+
+    def _agree(self, flag: int, group) -> bool:
+        """True iff every rank of the group passed a non-zero flag (one MIN all-reduce)."""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
 
     def _view(self, ptr, shape):
         from .mppi import _DevArray

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BN_MPPI_ABI_VERSION 3
+#define BN_MPPI_ABI_VERSION 4
 
 typedef enum bn_status {
     BN_OK = 0,
@@ -187,6 +187,19 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
  * (optimal_action_seq, optimal_state_seq) tensors the reference returns, without another launch. */
 int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise,
                           float *out_device);
+/* The same with the states taken from HOST memory, by value, at the call (ABI 4): the loop of test_mppi.py:174-181 whose environment
+ * lives on the host has a fresh state every control step, and `state.to(device)` in front of forward() (mppi.py:140-144) is an
+ * upload the solve then waits for.  states_host (B,3) may be reused as soon as the call returns.  One instance on the latency
+ * kernel: the state travels in the kernel arguments -- no copy is enqueued, and the kernel's prologue has no fetch in front of its
+ * window; other configurations stage and upload it (as bn_mppi_solve_async does for BN_MEM_HOST).
+ * ONE LAUNCH per call (both entry points, and bn_mppi_solve) where the latency kernel serves the handle (bn_mppi_launches_per_forward):
+ * the tail of the solve -- softmin merge, U*, the first-action mailbox (bn_mppi_first_action), X*, the weights -- is a workgroup of
+ * the rollout launch itself that waits on the device for the rollout workgroups dispatched in front of it; results are bit-identical
+ * to the two-launch path's.  That wait is bounded like every device-side wait of the library and cannot expire short of a stalled
+ * GPU; if it does, the next call that concerns results returns BN_ERR_HIP (the latest solve's outputs are invalid) and the handle
+ * keeps to two launches from then on. */
+int bn_mppi_forward_state_async(bn_mppi_t *h, const float *states_host, const float *eps_device, bn_noise_kind noise,
+                                float *out_device);
 /* n dependent solves enqueued from one call (the warm start chains them on the device; the state is
  * re-read from `states` by every solve).  Noise block i is eps + (i % eps_ring) * eps_stride floats.
  * With n >= 3 (and device-resident inputs) the solves of one call alternate between the handle's stream and an internal one and
@@ -255,6 +268,11 @@ int bn_mppi_shard_finish_async(bn_mppi_t *h, const float *all_partials_device, i
  * (bn_mppi_flush, bn_mppi_sync, any getter, bn_mppi_device_buffer), which enqueues the join without blocking the host. */
 #define BN_DIST_UNIQUE_ID_BYTES 128
 int bn_dist_unique_id(uint8_t out[BN_DIST_UNIQUE_ID_BYTES]);
+/* Everything bn_mppi_shard_comm_init can fail on short of the collective itself, done locally (ABI 4): RCCL opened, the handle's state
+ * checked, the gathered-rows buffer, the events and the side stream created.  A job calls it on every rank, agrees on the outcome
+ * (one all-reduce over the process group it has anyway) and enters bn_mppi_shard_comm_init -- ncclCommInitRank, which blocks until
+ * EVERY rank has entered -- only if all of them are ready.  bn_mppi_shard_comm_init calls it itself when the caller has not. */
+int bn_mppi_shard_comm_prepare(bn_mppi_t *h, int32_t world_size, int32_t rank);
 int bn_mppi_shard_comm_init(bn_mppi_t *h, const uint8_t unique_id[BN_DIST_UNIQUE_ID_BYTES], int32_t world_size, int32_t rank);
 int bn_mppi_shard_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_where, const float *eps, bn_noise_kind noise);
 /*
@@ -381,6 +399,9 @@ uint64_t bn_mppi_solve_count(const bn_mppi_t *h);
  * (BN_FLAG_REFERENCE_ORDER, or selected because dt * max|omega| > 0.5).  Kernel launches one solve costs: 1 or 2. */
 int32_t bn_mppi_arithmetic(const bn_mppi_t *h);
 int32_t bn_mppi_launches_per_solve(const bn_mppi_t *h);
+/* Kernel launches of one bn_mppi_forward_async / bn_mppi_forward_state_async / bn_mppi_solve call (solve AND its tail): 1 on the
+ * latency kernel (see bn_mppi_forward_state_async), else 2. */
+int32_t bn_mppi_launches_per_forward(const bn_mppi_t *h);
 /* How the cell index divides by the resolution (grid_map.py:203): 2 = exact multiplication (power-of-two resolution), 1 = the
  * three-instruction correctly rounded quotient, validated exhaustively on the device at create for this resolution and these limits
  * (bn_mppi_create refuses a resolution that fails the check; none is known). */

@@ -119,6 +119,46 @@ def test_library_enqueued_exchange_protocol_and_results():
         assert np.array_equal(a.states(), b.states())
 
 
+def test_library_enqueued_exchange_at_config5_size_takes_the_two_level_merge():
+    """BASELINE configs[4] (K=16384, T=100, 512x512): 256 partial rows, so the merge kernel of the library-enqueued exchange is the
+    multi-workgroup one -- 16 groups of 16 rows, the last workgroup to take its ticket merges the group rows (shard_merge_kernel, nblk > 64).
+    A chain of warm-started solves on a communicator of one rank against (a) the three-call protocol and (b) the UNSHARDED planner:
+    U*, X*, weights, costs, mean bit for bit at every step (this path had a rate check only)."""
+    import torch
+    from benchnav_amd import NativeMPPI, _capi, synth
+    from benchnav_amd.sharding import unique_id
+    from benchnav_amd.mppi import _DevArray
+    K, T, G = 16384, 100, 512
+    inst = synth.make_instance(G, seed=2)
+    st = inst.start.cuda()
+
+    def outs(pl):
+        pl.flush()
+        blk = torch.as_tensor(_DevArray(pl.device_buffer(_capi.BN_BUF_USTAR_XSTAR)[0], (T * 2 + (T + 1) * 3,)), device="cuda")
+        torch.cuda.synchronize(); pl.sync()
+        return blk.cpu().numpy().copy(), pl.weights(), pl.costs(), pl.get_mean()
+
+    with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=5, stream=0) as a, \
+         NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=5, stream=0) as b, \
+         NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=5, stream=0) as c:
+        for pl in (a, b, c):
+            pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+        a.shard_comm_prepare(1, 0)
+        a.shard_comm_init(unique_id(), 1, 0)
+        for i in range(6):                                   # past kSlots = 4: every rotating per-solve slot is reused
+            a.shard_solve_async_device(st.data_ptr())
+            b.shard_rollout_async_device(st.data_ptr())
+            ptr, n, ps = b.shard_partials()
+            assert n == 256
+            b.shard_finish_async(ptr, n)
+            c.forward_async_device(st.data_ptr())
+            oa, ob, oc = outs(a), outs(b), outs(c)
+            for j in range(4):
+                assert np.array_equal(oa[j], ob[j]), (i, j, "fused vs three calls")
+                assert np.array_equal(oa[j], oc[j]), (i, j, "fused vs unsharded")
+        assert np.array_equal(a.states(), c.states())
+
+
 def _dist_worker(rank, world, port, q):
     import os
     import torch

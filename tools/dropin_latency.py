@@ -7,9 +7,14 @@ import torch
 from helpers import load_case, mppi_for_fixture
 torch.set_num_threads(1)
 fx = load_case("c2")
-for mode, copy, lean in (("torch", True, False), ("torch_device", True, False), ("philox", True, False), ("philox", False, False), ("philox", False, True)):
+import sys as _sys
+quick = "--quick" in _sys.argv
+combos = ((("philox", True, False, "cpu"), ("philox", True, False, "cuda"), ("philox", False, False, "cpu")) if quick else
+          (("torch", True, False, "cuda"), ("torch_device", True, False, "cuda"), ("philox", True, False, "cuda"), ("philox", True, False, "cpu"),
+           ("philox", False, False, "cuda"), ("philox", False, False, "cpu"), ("philox", False, True, "cpu")))
+for mode, copy, lean, where in combos:
     solver = mppi_for_fixture(fx, noise=mode, copy_outputs=copy, store_controls=False, lean=lean)
-    state = torch.tensor(fx["state_0"], device="cuda")
+    state = torch.tensor(fx["state_0"], device=where)      # "cpu": the host loop's state, taken by value (bn_mppi_forward_state_async)
     for _ in range(50): U, X = solver(state)
     torch.cuda.synchronize(); n = 500
     host = 0.0
@@ -32,5 +37,5 @@ for mode, copy, lean in (("torch", True, False), ("torch_device", True, False), 
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): U, X = solver(state)
     torch.cuda.synchronize(); dq = (time.perf_counter() - t) / n
-    print(f"noise={mode:12s} copy_outputs={copy!s:5s} lean={lean!s:5s}: forward() host {host / n * 1e6:6.1f} us | forward()+readback {dt * 1e6:6.1f} us "
+    print(f"noise={mode:12s} copy_outputs={copy!s:5s} lean={lean!s:5s} state={where:4s}: forward() host {host / n * 1e6:6.1f} us | forward()+readback {dt * 1e6:6.1f} us "
           f"({1 / dt:.0f} Hz) | forward()+first_action() {dm * 1e6:6.1f} us ({1 / dm:.0f} Hz) | back-to-back {dq * 1e6:6.1f} us", flush=True)
