@@ -636,8 +636,9 @@ def dropin_forward(inst, dev, n_steps):
     """The path a BenchNav user gets after changing the import: `benchnav_amd.MPPI(...)` built from reference-shaped `dynamics` /
     `objectives` objects and driven as the reference's loop drives it (test/test_mppi.py:174-181) -- one `forward(state)` per control
     step, the state living on the HOST and changing every step, the host consuming `action_seq[0]` before it can take the next step.
-    Per step: forward() (ONE launch on the latency kernel: rollouts and the solve's own tail, bn_mppi_forward_state_async -- the state
-    travels in the kernel arguments), first_action() (polls the tail's pinned-memory mailbox: no stream synchronisation, no copy), and a
+    Per step: forward() (ONE launch on the latency kernel: rollouts and the solve's own tail, bn_mppi_forward_state_async; with
+    host_loop=True that launch was enqueued one step ahead and waits on the device for the state this call posts to pinned memory),
+    first_action() (polls the tail's pinned-memory mailbox: no stream synchronisation, no copy), and a
     host-side environment step (the unicycle transit of planetary_env.py:203-205 on three Python floats with a nearest-cell lookup in the
     host copy of the risk map).  Also timed: the unmodified reference loop's read-back, `action_seq[0].cpu()`."""
     import math
@@ -650,8 +651,10 @@ def dropin_forward(inst, dev, n_steps):
     dyn = types.SimpleNamespace(_grid_map=gm, _traversability_model=types.SimpleNamespace(_risks=inst.risk), _model_config=types.SimpleNamespace(mode="inference"),
                                 min_action=torch.tensor([0.0, -1.0]), max_action=torch.tensor([1.0, 1.0]))
     obj = types.SimpleNamespace(_goal_pos=inst.goal, _stuck_threshold=0.3, stage_cost=None, terminal_cost=None)
-    solver = MPPI(horizon=T, num_samples=K, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, sigmas=torch.tensor([0.5, 0.5]), lambda_=0.5,
-                  device=torch.device("cuda", dev), seed=42, noise="philox", store_controls=False)
+    def make(host_loop):
+        return MPPI(horizon=T, num_samples=K, dim_state=3, dim_control=2, dynamics=dyn, objectives=obj, sigmas=torch.tensor([0.5, 0.5]), lambda_=0.5,
+                    device=torch.device("cuda", dev), seed=42, noise="philox", store_controls=False, host_loop=host_loop)
+    solver = solver_paced = make(True)
     risk = inst.risk.numpy()
     state = inst.start.clone()                           # a CPU tensor, rewritten in place every step (forward() takes it by value)
     sv = state.numpy()
@@ -665,7 +668,8 @@ def dropin_forward(inst, dev, n_steps):
         sv[1] = min(max(y + trav * a0 * math.sin(th) * 0.1, 0.0), hi)
         sv[2] = (th + trav * a1 * 0.1 + math.pi) % (2 * math.pi) - math.pi
 
-    def loop(n, readback):
+    def loop(n, readback, solver=None):
+        solver = solver or solver_paced
         t_f = t_a = t_e = 0.0
         sv[:] = s0
         torch.cuda.synchronize()
@@ -683,12 +687,17 @@ def dropin_forward(inst, dev, n_steps):
             td = time.perf_counter()
             t_f += tb - ta; t_a += tc - tb; t_e += td - tc
         wall = time.perf_counter() - t0
+        solver.release()                                 # ends the loop: a launch waiting for the next state is cancelled (host_loop)
         torch.cuda.synchronize()
         return wall / n, t_f / n, t_a / n, t_e / n
 
     loop(200, False)
     best = min((loop(n_steps, False) for _ in range(3)), key=lambda r: r[0])
     rb = min((loop(max(n_steps // 2, 300), True) for _ in range(2)), key=lambda r: r[0])
+    plain = make(False)                                  # the same loop without the opt-in: one ordinary launch per forward()
+    loop(200, False, plain)
+    one = min((loop(n_steps, False, plain) for _ in range(3)), key=lambda r: r[0])
+    del plain
     lpf = int(solver._lib.bn_mppi_launches_per_forward(solver._handle))
     # cross-check of what the loop consumed: the mailbox value IS action_seq[0]
     U, X = solver.forward(state)
@@ -696,10 +705,13 @@ def dropin_forward(inst, dev, n_steps):
     return {"value": 1.0 / best[0], "unit": "control steps/s", "us_per_step": best[0] * 1e6, "steps": n_steps,
             "split_us": {"forward_call_host": best[1] * 1e6, "first_action_wait": best[2] * 1e6, "host_env_step": best[3] * 1e6,
                          "loop_overhead": (best[0] - best[1] - best[2] - best[3]) * 1e6},
-            "launches_per_forward": lpf, "first_action_equals_action_seq0": same,
+            "launches_per_forward": lpf, "first_action_equals_action_seq0": same, "host_loop": bool(solver._host_loop),
+            "without_host_loop": {"value": 1.0 / one[0], "us_per_step": one[0] * 1e6,
+                                  "split_us": {"forward_call_host": one[1] * 1e6, "first_action_wait": one[2] * 1e6, "host_env_step": one[3] * 1e6},
+                                  "note": "MPPI(host_loop=False), the default: one launch per forward() (rollouts + the solve's own tail), enqueued when forward() is called"},
             "with_cpu_readback": {"value": 1.0 / rb[0], "us_per_step": rb[0] * 1e6,
                                   "note": "the unmodified reference loop: action_seq[0].cpu() instead of first_action() -- a stream synchronisation and a copy"},
-            "config": {"class": "benchnav_amd.MPPI (drop-in for src/planners/local_planners/mppi.py:MPPI)", "noise": "philox", "copy_outputs": True,
+            "config": {"class": "benchnav_amd.MPPI (drop-in for src/planners/local_planners/mppi.py:MPPI)", "noise": "philox", "copy_outputs": True, "host_loop": True,
                        "state": "host (CPU tensor), new every control step", "workload": "BASELINE configs[1]: K=1024, T=50, 256x256"},
             "note": "one solve per step with the host in the loop: launch latency, the whole solve's latency and the mailbox's trip to the host are "
                     "paid every step, nothing overlaps -- the reference boundary's figure; `value` above is the device-side chain of dependent solves"}

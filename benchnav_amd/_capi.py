@@ -27,6 +27,8 @@ BN_FLAG_LEAN = 512
 BN_FLAG_LAT_KERNEL = 1024
 BN_FLAG_NO_OVERLAP = 2048
 BN_FLAG_REFERENCE_ORDER = 4096
+BN_FLAG_HOST_PACED = 8192
+BN_BUF_STATES_ALT, BN_BUF_CONTROLS_ALT = 10, 11
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
 ABI_VERSION = 4
 
@@ -85,6 +87,7 @@ SYMBOLS = {
     "bn_mppi_first_action": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_debug_expire_wait": (C.c_int, [_H]),
     "bn_mppi_flush": (C.c_int, [_H]),
+    "bn_mppi_debug_host_paced": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "bn_mppi_get_weights": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_get_costs": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_get_states": (C.c_int, [_H, C.c_int32, _FP]),
@@ -97,6 +100,8 @@ SYMBOLS = {
     "bn_mppi_arithmetic": (C.c_int32, [_H]),
     "bn_mppi_launches_per_solve": (C.c_int32, [_H]),
     "bn_mppi_launches_per_forward": (C.c_int32, [_H]),
+    "bn_mppi_host_paced": (C.c_int32, [_H]),
+    "bn_mppi_states_buffer_index": (C.c_int32, [_H]),
     "bn_mppi_fast_quotient": (C.c_int32, [_H]),
     "bn_mppi_row_pitch": (C.c_int32, [_H]),
     "bn_mppi_kernel_ms": (C.c_int, [_H, _FP, _FP, C.POINTER(C.c_int32)]),

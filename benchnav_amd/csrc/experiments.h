@@ -37,7 +37,7 @@
 #define BN_TIMING_DO(...) __VA_ARGS__
 // the self tail of a one-launch forward (finish_body<.., SELF>): chip-wide 100 MHz clock of instance 0's tail workgroup at stamps[900 + i]
 // (tools/stamps_forward.py); the rollout workgroup (0, 0) of the same launch leaves its own at stamps[32 + 16 parity + slot]
-#define BN_SSTAMP(i) do { if (SELF && p.stamps && threadIdx.x == 0 && b == 0) p.stamps[900 + (i)] = wall_clock64(); } while (0)
+#define BN_SSTAMP(i) do { if (SELF && p.stamps && threadIdx.x == 0 && b == 0) p.stamps[900 + 16 * (p.tail_solve & 1) + (i)] = wall_clock64(); } while (0)
 #else
 #define BN_SSTAMP(i) do { } while (0)
 #define BN_TIMING_DO(...)

@@ -214,6 +214,27 @@ struct bn_mppi {
     bool self_tail_launched = false; // the latest solve_impl call took the one-launch path (its tail is NOT pending)
     bool self_used = false;          // a self tail's bounded wait could have expired since the error word was last looked at
     bool self_off = false;           // ... and one did: two launches per synchronous solve from then on
+    // Host-paced loop (BN_FLAG_HOST_PACED, round 6): bn_mppi_forward_state_async enqueues the NEXT solve's launch one control step ahead,
+    // on one of two private streams; that launch waits on the device for the state the next call posts (rollout_lat.inc, HOSTP).
+    bool hp_enabled = false;
+    hipStream_t hp_stream[2] = {};   // [0] = xstream[0], [1] = xstream[1] (created for this mode); the launches alternate
+    hipEvent_t hp_ev[2] = {};        // recorded behind every prelaunch; the handle's stream waits for it when the request is posted
+    unsigned long long *h_req = nullptr, *d_req = nullptr;         // pinned: kSlots x 8 request granules + (at [kSlots * 8]) the give-up word
+    unsigned long long *d_req_dev = nullptr;                       // device: kSlots x 8, republished by the launches' tail workgroups
+    uint32_t hp_seq = 0;             // request tags, unique per prelaunch
+    bool hp_armed = false;           // a prelaunched solve waits for its state
+    uint32_t hp_tag = 0;             // ... its tag, request slot, stream index, trajectory buffer
+    int hp_slot = 0, hp_q = 0, hp_xidx = 0;
+    uint32_t hp_posted_tag = 0;      // the latest request posted (bn_mppi_first_action watches the give-up word for it)
+    float hp_posted_state[3] = {};
+    float *hp_posted_out = nullptr;
+    bool hp_skip_check = false;      // test hook: post without looking whether the launch has given up (exercises the repair in bn_mppi_first_action)
+    float hp_prev_state[3] = {};     // the state of the latest forward (the next launch's speculative window is staged around it)
+    bool hp_gran_valid = false;      // the latest solve published its partial rows as granules and nothing has touched the mean since
+    int hp_extra = 2;                // cells the speculative window is wider on each side
+    int x_idx = 0;                   // which trajectory / control buffer holds the latest solve (bn_mppi_states_buffer_index)
+    int hp_next_q = 0;
+    int hp_polls = 25000;            // how long a prelaunched solve waits for its state: looks of ~2 us each (~50 ms); bn_mppi_debug_host_paced
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
     bool shard_pending = false;      // K-sharded solve: rollouts launched, tail waits for the partials of the other shards
@@ -274,6 +295,8 @@ size_t buffer_bytes(const bn_mppi *h, bn_buffer_id id)
     const size_t B = h->p.B, K = h->p.K, T = h->p.T, G = h->p.G;
     switch (id) {
     case BN_BUF_STATES: return B * (T + 1) * 3 * (size_t)h->p.Kp * 4;
+    case BN_BUF_STATES_ALT: return h->d_Xalt[0] ? B * (T + 1) * 3 * (size_t)h->p.Kp * 4 : 0;
+    case BN_BUF_CONTROLS_ALT: return h->d_Ualt[0] ? B * T * 2 * (size_t)h->p.Kp * 4 : 0;
     case BN_BUF_WEIGHTS: return B * K * 4;
     case BN_BUF_COSTS: return B * K * 4;
     case BN_BUF_CONTROLS: return h->d_U ? B * T * 2 * (size_t)h->p.Kp * 4 : 0;
@@ -299,6 +322,40 @@ int ensure_scratch(bn_mppi *h, size_t bytes)
 }
 
 int guard_foreign_overlap(bn_mppi *h);      // (defined with order_behind_foreign_overlap)
+
+// ---- host-paced loop: the request words --------------------------------------------------------------------------------------
+// A request is six {value, tag} granules in pinned memory (x, y, theta, the caller's output block lo / hi, the command); the
+// launch's tail workgroup takes them when all six carry the launch's tag.  Plain 8-byte stores: x86 keeps them in order, and each
+// granule vouches for itself anyway.
+void hp_write_request(bn_mppi *h, int slot, uint32_t tag, const float st[3], const float *out, uint32_t cmd)
+{
+    unsigned long long *r = h->h_req + (size_t)slot * 8;
+    uint32_t w[6] = {0, 0, 0, 0, 0, cmd};
+    if (st) std::memcpy(w, st, 12);
+    const unsigned long long o = (unsigned long long)(uintptr_t)out;
+    w[3] = (uint32_t)o; w[4] = (uint32_t)(o >> 32);
+    for (int i = 0; i < 6; ++i) __atomic_store_n(r + i, ((unsigned long long)tag << 32) | w[i], __ATOMIC_RELEASE);
+}
+
+// The tail workgroup of the launch with this tag gave up waiting for the host (~50 ms) and said so: the launch has ended, nothing happened.
+bool hp_gave_up(const bn_mppi *h, uint32_t tag)
+{
+    return tag != 0 && h->h_req && __atomic_load_n(h->h_req + (size_t)kSlots * 8, __ATOMIC_ACQUIRE) == (((unsigned long long)tag << 32) | 2ull);
+}
+
+// A launch that still waits for its state is told to leave -- it has touched nothing but its own LDS -- and the host's bookkeeping
+// goes back to where it was before the prelaunch.  No synchronisation: the launch ends by itself within a poll.
+void hp_cancel(bn_mppi *h)
+{
+    if (!h->hp_armed) return;
+    hp_write_request(h, h->hp_slot, h->hp_tag, nullptr, nullptr, 2u);
+    h->hp_armed = false;
+    h->solves -= 1;
+    const int cur3 = (int)(h->solves % kSlots);
+    h->pub[cur3] -= (unsigned long long)h->p.nblk;
+    h->tails -= 1;
+    h->hp_next_q = h->hp_q;                            // (the stream the cancelled launch leaves within a poll)
+}
 
 // Write the tail (U*, next mean, X*, weights, cost copy) of the latest solve if it is still pending.
 int flush_tail(bn_mppi *h, float *out_copy = nullptr)
@@ -473,6 +530,8 @@ int self_check(bn_mppi *h)
 // an expired wait could have spoilt is repaired first.  Free unless overlapped launches are outstanding (then: one synchronisation).
 int settle_point(bn_mppi *h)
 {
+    hp_cancel(h);                                      // (a launch waiting for the host's next state: this call is not that state)
+    h->hp_gran_valid = false;
     if (int rc = self_check(h)) return rc;
     if (!h->overlap_used || h->replaying) return BN_OK;
     if (int rc = flush_tail(h)) return rc;
@@ -829,6 +888,45 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         }
         (void)hipMemset(probe, 0, 2 * sizeof(int));
     }
+    // Host-paced loop (BN_FLAG_HOST_PACED): a second private stream that dispatches concurrently with the first, the request words, events
+    if (rc == BN_OK && (cfg->flags & BN_FLAG_HOST_PACED) && p.B == 1 && h->lat_kernel && h->d_gran[0] && may_overlap && !h->overlap_off &&
+        h->n_streams > 1 && h->xstream[0] && !p.slip_on && !(cfg->flags & (BN_FLAG_NO_PIPELINE | BN_FLAG_PROFILE))) {
+        {
+            bn::SolveParams q = p;
+            q.spec_extra = h->hp_extra;
+            if (bn::lat_lds_bytes(q) == 0) h->hp_extra = 0;        // no room for the wider window: every state but the previous one stages again
+        }
+        int *probe = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 1) * bn::kFlagStride);      // the spare counter slot
+        bool found = false, ok = hipStreamCreateWithFlags(&h->xstream[1], hipStreamNonBlocking) == hipSuccess;
+        for (int attempt = 0; ok && attempt < 8 && !found; ++attempt) {
+            int seen = 0;
+            ok = hipMemset(probe, 0, 2 * sizeof(int)) == hipSuccess && bn::launch_queue_probe(probe, h->xstream[0], h->xstream[1], h->n_cus) == hipSuccess &&
+                 hipStreamSynchronize(h->xstream[0]) == hipSuccess && hipStreamSynchronize(h->xstream[1]) == hipSuccess &&
+                 hipMemcpy(&seen, probe + 1, sizeof seen, hipMemcpyDeviceToHost) == hipSuccess;
+            if (!ok) break;
+            if (seen) { found = true; break; }
+            if (attempt == 7) break;
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+            h->parked.push_back(h->xstream[1]);
+            h->xstream[1] = fresh;
+        }
+        (void)hipGetLastError();
+        (void)hipMemset(probe, 0, 2 * sizeof(int));
+        if (ok && found) {
+            const size_t words = (size_t)kSlots * 8 + 8;
+            ok = hipHostMalloc((void **)&h->h_req, words * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess &&
+                 hipHostGetDevicePointer((void **)&h->d_req, h->h_req, 0) == hipSuccess;
+            if (ok) std::memset(h->h_req, 0, words * sizeof(unsigned long long));
+            alloc(&h->d_req_dev, (size_t)kSlots * 8 * sizeof(unsigned long long));
+            for (int q = 0; ok && q < 2; ++q) ok = hipEventCreateWithFlags(&h->hp_ev[q], hipEventDisableTiming) == hipSuccess;
+            if (ok && rc == BN_OK) {
+                h->hp_stream[0] = h->xstream[0]; h->hp_stream[1] = h->xstream[1];
+                h->hp_enabled = true;
+            }
+        }
+        (void)hipGetLastError();                       // (a handle that cannot pace keeps the one-launch path: bn_mppi_host_paced() tells)
+    }
     if (rc != BN_OK) {
         bn_mppi_destroy(h);
         return rc;
@@ -847,6 +945,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
 {
     if (!h) return;
     DeviceGuard guard(h->cfg.device_id);
+    hp_cancel(h);
     (void)hipStreamSynchronize(h->stream);
     {
         std::lock_guard<std::mutex> lock(g_overlap_mu);
@@ -885,6 +984,9 @@ void bn_mppi_destroy(bn_mppi_t *h)
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
+    if (h->h_req) (void)hipHostFree(h->h_req);
+    if (h->d_req_dev) (void)hipFree(h->d_req_dev);
+    for (hipEvent_t e : h->hp_ev) if (e) (void)hipEventDestroy(e);
     if (h->d_mean_snap) (void)hipFree(h->d_mean_snap);
     if (h->d_state_snaps) (void)hipFree(h->d_state_snaps);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1022,6 +1124,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
     if ((noise == BN_NOISE_PHILOX) != (eps == nullptr))
         return fail(BN_ERR_INVALID, "eps must be NULL exactly when noise == BN_NOISE_PHILOX");
     BN_BIND(h);
+    hp_cancel(h);                                      // (a host-paced launch waiting for a state: this solve is not it)
+    h->hp_gran_valid = false;
     if (!overlap && g_overlap_owners.load(std::memory_order_relaxed) > 0) {
         if (int rc = order_behind_foreign_overlap(h, on_stream ? on_stream : h->stream)) return rc;
     }
@@ -1146,6 +1250,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             h->self_used = true;
             h->self_tail_launched = true;
             h->prev_published = false;
+            h->hp_gran_valid = p.gran != nullptr;
+            h->x_idx = 0;
         } else
         if ((h->lat_kernel || h->role_overlap) && overlap) {   // member of an overlapped batch: publishes, and waits if its predecessor published
             p.flag_part = h->d_flags;
@@ -1183,6 +1289,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         BN_HIP(bn::launch_rollout(p, mode, st));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
+        h->x_idx = 0;                                  // (batches end on the exposed buffers, bn_mppi_solve_n_async)
         h->tail_pending = !p.self_tail;
         if (p.self_tail) h->prev_published = false;                // the next solve starts from the mean that tail writes, in stream order
         if (lone_self) h->last_batch_overlapped = false;
@@ -1266,6 +1373,107 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     return solve_impl(h, states, states_where, eps, noise, false);
 }
 
+// Host-paced loop: enqueue the launch of the solve AFTER the latest one, on a private stream; it waits on the device for its state.
+// Best effort: returns false (and leaves nothing behind) when the handle's state does not allow it.
+static bool hp_prelaunch(bn_mppi *h)
+{
+    if (!h->hp_enabled || h->hp_armed || h->self_off || !h->hp_gran_valid || h->tail_pending || h->shard_pending || h->in_episode || h->replaying ||
+        !h->map_set || !h->goal_set || h->solves == 0)
+        return false;
+    {   // not beside another handle's launches (the latency kernel is sized for a device it has to itself: see g_handles)
+        std::lock_guard<std::mutex> lock(g_overlap_mu);
+        for (bn_mppi *o : g_handles[h->cfg.device_id]) {
+            if (o == h) continue;
+            for (int q = 0; q < kMaxStreams; ++q) {
+                const hipStream_t os = q ? o->xstream[q - 1] : o->stream;
+                if ((q && !os) || os == h->stream) continue;
+                if (hipStreamQuery(os) != hipSuccess) { (void)hipGetLastError(); return false; }
+            }
+        }
+        (void)hipGetLastError();
+    }
+    bn::SolveParams p = h->p;
+    const size_t B = 1;
+    const int cur3 = (int)(h->solves % kSlots), prev3 = (int)((h->solves + kSlots - 1) % kSlots);
+    p.solve = h->solves; p.tail_solve = p.solve;
+    p.part = h->d_part[cur3]; p.cost = h->d_cost[cur3]; p.state_copy = h->d_state_copy[cur3];
+    p.part_prev = h->d_part[prev3]; p.cost_prev = h->d_cost[prev3]; p.state_prev = h->d_state_copy[prev3];
+    p.have_prev = 0; p.mean_from_part = 1;             // the mean IS the merge of the previous solve's rows (its tail writes the same values)
+    p.lat_kernel = 1; p.wave_kernel = 0;
+    p.flag_tail = h->d_flags + kSlots * B * bn::kFlagStride;
+    p.flag_part = h->d_flags;
+    p.err = h->d_err; p.err_dev = reinterpret_cast<int *>(h->d_flags + ((kSlots + 1) * B + 2) * bn::kFlagStride);
+    p.cur_slot = cur3; p.prev_slot = prev3;
+    p.wait_part = h->pub[prev3];
+    p.gran = h->d_gran[cur3]; p.gran_prev = h->d_gran[prev3];
+    p.overlap = 1;
+    p.self_tail = 1;
+    p.wait_part_self = h->pub[cur3] + (unsigned long long)p.nblk;
+    p.wait_tail_self = h->tails;
+    const int xi = 1 - h->x_idx;                       // the other trajectory / control buffer: two launches in flight never write the same addresses
+    if (xi && h->d_Xalt[0]) p.X = h->d_Xalt[0];
+    if (!p.store_u) p.U = nullptr;
+    else if (xi && h->d_Ualt[0]) p.U = h->d_Ualt[0];
+    p.host_paced = 1;
+    std::memcpy(p.sv, h->hp_prev_state, 12);
+    p.spec_extra = h->hp_extra;
+    const uint32_t tag = h->hp_seq + 1;
+    const int slot = (int)(tag % kSlots);
+    static_assert(kSlots == 4, "the kernels acknowledge a request in word 1 + (tag & 3)");
+    if (tag > (uint32_t)kSlots) {
+        // The slot's previous user -- the launch four tags back -- must have taken (or given up on) its request before the words are
+        // written again: its tail workgroup says so.  In a loop paced by bn_mppi_first_action that was three solves ago; a caller that
+        // fires forwards back to back is held to the device's pace here (bounded: a launch gives up by itself after ~50 ms).
+        const unsigned long long *ack = h->h_req + (size_t)kSlots * 8 + 1 + slot;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long it = 0; __atomic_load_n(ack, __ATOMIC_ACQUIRE) != (unsigned long long)(tag - kSlots); ++it)
+            if ((it & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { h->hp_enabled = false; return false; }
+    }
+    h->hp_seq = tag;
+    p.req_tag = tag;
+    p.req_polls = h->hp_polls;                         // ~50 ms at ~2 us a look
+    p.req_host = h->d_req + (size_t)slot * 8;
+    p.req_dev = h->d_req_dev + (size_t)slot * 8;
+    p.spec_status = h->d_req + (size_t)kSlots * 8;
+    p.state = h->d_state;                              // (not read: the state comes with the request)
+    const int q = h->hp_next_q;
+    const hipError_t e = p.ref_order ? bn::launch_rollout_lat_host_ref(p, h->hp_stream[q]) : bn::launch_rollout_lat_host(p, h->hp_stream[q]);
+    if (e != hipSuccess) { (void)hipGetLastError(); h->hp_enabled = false; return false; }
+    if (hipEventRecord(h->hp_ev[q], h->hp_stream[q]) != hipSuccess) (void)hipGetLastError();
+    h->pub[cur3] += (unsigned long long)p.nblk;
+    h->tails += 1;
+    h->solves += 1;
+    h->hp_armed = true; h->hp_tag = tag; h->hp_slot = slot; h->hp_q = q; h->hp_xidx = xi;
+    h->hp_next_q = 1 - q;
+    return true;
+}
+
+// ... and hand the waiting launch its state.
+static int hp_post(bn_mppi *h, const float st[3], float *out_device)
+{
+    // The waiting launch runs on a stream of its own: it is ordered behind the HOST (this store), not behind what the caller enqueued on
+    // the handle's stream before this call.  The contract of the mode (header): work left there that still reads the planner's own
+    // buffers -- weights, trajectory batch, the shared U* | X* block -- or the last users of the memory `out_device` was carved from must
+    // have completed; fresh output blocks per step (what the drop-in class hands out) need nothing.  (Asking the stream -- hipStreamQuery
+    // -- is no way out: the event that orders the previous solve's launch in front of the caller's consumers keeps it "busy" for tens of
+    // microseconds after that launch has ended, and every step would wait for it: 17 -> 39 us, measured.)
+    hp_write_request(h, h->hp_slot, h->hp_tag, st, out_device, 1u);
+    h->hp_armed = false;
+    h->hp_posted_tag = h->hp_tag;
+    std::memcpy(h->hp_posted_state, st, 12);
+    h->hp_posted_out = out_device;
+    std::memcpy(h->hp_prev_state, st, 12);
+    h->x_idx = h->hp_xidx;
+    h->map_epoch_at_solve = h->map_epoch;
+    h->last_eps = nullptr; h->last_mode = bn::kEpsPhilox;
+    h->tail_pending = false; h->prev_published = false; h->last_batch_overlapped = false;
+    h->self_used = true;
+    h->hp_gran_valid = true;
+    // whatever the caller enqueues on the handle's stream from here on is ordered behind this solve's launch (its outputs)
+    BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[h->hp_q], 0));
+    return BN_OK;
+}
+
 // MPPI.forward as ONE call -- and, on the latency kernel, ONE launch: the solve's tail (merge -> U* -> first-action mailbox -> X* ->
 // weights) rides in the rollout launch as a second aux workgroup that waits on the device for the rollout workgroups of its own launch.
 static int forward_impl(bn_mppi_t *h, const float *states_device, const float *state_host, const float *eps_device, bn_noise_kind noise,
@@ -1273,6 +1481,16 @@ static int forward_impl(bn_mppi_t *h, const float *states_device, const float *s
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     if (!states_device && !state_host) return fail(BN_ERR_INVALID, "states is null");
+    if ((noise == BN_NOISE_PHILOX) != (eps_device == nullptr)) return fail(BN_ERR_INVALID, "eps must be NULL exactly when noise == BN_NOISE_PHILOX");
+    const bool paced = h->hp_enabled && state_host && noise == BN_NOISE_PHILOX && !h->self_off;
+    if (paced && h->hp_armed && !h->hp_skip_check && hp_gave_up(h, h->hp_tag)) hp_cancel(h);      // (the host took longer than the launch waits: start over below)
+    if (paced && h->hp_armed) {                        // the loop's steady state: the launch is there and waits for exactly this
+        BN_BIND(h);
+        if (int rc = self_check(h)) return rc;
+        if (int rc = hp_post(h, state_host, out_device)) return rc;
+        (void)hp_prelaunch(h);                         // ... and the next one goes out while this one runs
+        return BN_OK;
+    }
     {
         BN_BIND(h);
         if (int rc = settle_point(h)) return rc;       // behind overlapped batches: those are checked (one synchronisation) first
@@ -1289,7 +1507,14 @@ static int forward_impl(bn_mppi_t *h, const float *states_device, const float *s
     h->self_out_copy = nullptr;
     h->inline_state = nullptr;
     if (rc0) return rc0;
-    if (h->self_tail_launched) return BN_OK;           // tail and the caller's copy ride in the launch
+    if (h->self_tail_launched) {                       // tail and the caller's copy ride in the launch
+        if (paced && by_value) {
+            BN_BIND(h);
+            std::memcpy(h->hp_prev_state, state_host, 12);
+            (void)hp_prelaunch(h);
+        }
+        return BN_OK;
+    }
     BN_BIND(h);
     if (!h->tail_pending && out_device) {              // two-launch modes: the tail has run; one small copy on the stream
         const size_t n = (size_t)h->p.B * ((size_t)h->p.T * 2 + ((size_t)h->p.T + 1) * 3);
@@ -1297,6 +1522,21 @@ static int forward_impl(bn_mppi_t *h, const float *states_device, const float *s
         return BN_OK;
     }
     return flush_tail(h, out_device);
+}
+
+// The launch a request was posted to had given up a moment before (its tail workgroup said so after the post): the solve never ran.
+// Take it -- and a successor prelaunched behind it -- out of the books and run it again the ordinary way, from the same state.
+static int hp_redo(bn_mppi *h)
+{
+    hp_cancel(h);
+    h->solves -= 1;
+    h->pub[h->solves % kSlots] -= (unsigned long long)h->p.nblk;
+    h->tails -= 1;
+    h->hp_posted_tag = 0;
+    h->hp_gran_valid = false;
+    float st[3];
+    std::memcpy(st, h->hp_posted_state, 12);
+    return forward_impl(h, nullptr, st, nullptr, BN_NOISE_PHILOX, h->hp_posted_out);
 }
 
 int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float *eps_device, bn_noise_kind noise, float *out_device)
@@ -1577,7 +1817,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         for (bn_mppi *o : g_handles[h->cfg.device_id]) {   // ... and is every other handle idle?  (see g_handles)
             if (!mine) break;
             if (o == h) continue;
-            for (int q = 0; mine && q < std::max(o->n_streams, 1); ++q) {
+            for (int q = 0; mine && q < kMaxStreams; ++q) {            // (incl. the second private stream of a host-paced handle)
                 const hipStream_t os = q ? o->xstream[q - 1] : o->stream;
                 if ((q && !os) || os == h->stream) continue;
                 if (hipStreamQuery(os) != hipSuccess) mine = false;
@@ -1949,6 +2189,7 @@ int bn_mppi_sync(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
+    hp_cancel(h);
     if (int rc = flush_tail(h)) return rc;
     if (int rc = sync_checked(h)) return rc;            // a bounded device-side wait of an overlapped launch may have expired: see recover_overlap
     return self_check(h);
@@ -1966,9 +2207,14 @@ int bn_mppi_first_action(bn_mppi_t *h, int32_t instance, float action_host[2])
     if (int rc = flush_tail(h)) return rc;                  // the tail is what posts it
     // The tail writes U*[0] to pinned host memory as soon as its merge is done -- two {value, tag} granules, tag = solve index + 1
     // -- and goes on with X* and the weights; the host polls the granules: no stream synchronisation, no copy.
-    const uint32_t want = (uint32_t)h->solves;
+    uint32_t want = (uint32_t)(h->solves - (h->hp_armed ? 1 : 0));      // (a launch that waits for the NEXT state is not the latest solve)
     const volatile unsigned long long *m = h->h_mail + 2 * (size_t)instance;
     for (long it = 0;; ++it) {
+        if ((it & 0xff) == 0xff && h->hp_posted_tag && hp_gave_up(h, h->hp_posted_tag)) {      // host-paced: the request went to a launch that had just given up
+            if (int rc = hp_redo(h)) return rc;
+            want = (uint32_t)(h->solves - (h->hp_armed ? 1 : 0));
+        }
+
         const unsigned long long a = m[0], b = m[1];
         if ((uint32_t)(a >> 32) == want && (uint32_t)(b >> 32) == want) {
             const uint32_t ua = (uint32_t)a, ub = (uint32_t)b;
@@ -2000,6 +2246,7 @@ int bn_mppi_debug_expire_wait(bn_mppi_t *h)
     // caller that gets valid results afterwards got them from the re-run.
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
+    hp_cancel(h);
     if (int rc = flush_tail(h)) return rc;
     BN_HIP(hipStreamSynchronize(h->stream));
     const size_t B = h->p.B, K = h->p.K, T = h->p.T;
@@ -2019,10 +2266,24 @@ int bn_mppi_debug_expire_wait(bn_mppi_t *h)
     return BN_OK;
 }
 
+int bn_mppi_debug_host_paced(bn_mppi_t *h, int32_t polls, int32_t post_unchecked)
+{
+    // Test hook: how many looks (~2 us each) a prelaunched solve waits for its state before it gives up (default 25000), and whether the
+    // host posts without checking that the launch is still there -- with one look the launch is gone before any host can answer, and
+    // an unchecked post lands in the repair path of bn_mppi_first_action.
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    if (polls < 1) return fail(BN_ERR_INVALID, "polls must be >= 1");
+    h->hp_polls = polls;
+    h->hp_skip_check = post_unchecked != 0;
+    return BN_OK;
+}
+
 int bn_mppi_flush(bn_mppi_t *h)
 {
     if (!h) return fail(BN_ERR_INVALID, "null handle");
     BN_BIND(h);
+    hp_cancel(h);
+    h->hp_gran_valid = false;                          // (the caller may write the mean buffer next: the class's _previous_action_seq setter)
     if (int rc = flush_tail(h)) return rc;
     // no synchronisation here; but an expiry that has ALREADY happened is repaired now rather than at the next synchronising call
     return (h->overlap_used && !h->replaying && __atomic_load_n(h->h_err, __ATOMIC_ACQUIRE)) ? settle_overlap(h, false) : BN_OK;
@@ -2111,7 +2372,7 @@ int bn_mppi_get_states(bn_mppi_t *h, int32_t instance, float *out_host)
     if (h->p.lean) {                                   // not materialised: regenerate all K rows
         if (int rc = reroll_rows(h, instance, nullptr, (int32_t)K, h->d_scratch)) return rc;
     } else
-    BN_HIP(bn::launch_states_to_reference(h->d_X + (size_t)instance * Kp * T1 * 3, h->d_scratch, (int)K, (int)Kp, (int)T1,
+    BN_HIP(bn::launch_states_to_reference((h->x_idx && h->d_Xalt[0] ? h->d_Xalt[0] : h->d_X) + (size_t)instance * Kp * T1 * 3, h->d_scratch, (int)K, (int)Kp, (int)T1,
                                           h->stream));
     BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
@@ -2127,7 +2388,7 @@ int bn_mppi_get_controls(bn_mppi_t *h, int32_t instance, float *out_host)
     if (int rc = settle_point(h)) return rc;
     const size_t K = h->p.K, Kp = h->p.Kp, T = h->p.T, n = K * T * 2;
     if (int rc = ensure_scratch(h, n * 4)) return rc;
-    BN_HIP(bn::launch_controls_to_reference(h->d_U + (size_t)instance * Kp * T * 2, h->d_scratch, (int)K, (int)Kp, (int)T,
+    BN_HIP(bn::launch_controls_to_reference((h->x_idx && h->d_Ualt[0] ? h->d_Ualt[0] : h->d_U) + (size_t)instance * Kp * T * 2, h->d_scratch, (int)K, (int)Kp, (int)T,
                                             h->stream));
     BN_HIP(hipMemcpyAsync(out_host, h->d_scratch, n * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
@@ -2194,7 +2455,7 @@ int bn_mppi_get_top_samples(bn_mppi_t *h, int32_t instance, int32_t n, float *st
     if (h->p.lean) {                                   // the n winners are re-rolled, bit-identical to a stored batch
         if (int rc = reroll_rows(h, instance, h->d_idx, n, h->d_scratch)) return rc;
     } else
-    BN_HIP(bn::launch_gather_states(h->d_X + (size_t)instance * h->p.Kp * T1 * 3, h->d_idx, h->d_scratch, n, h->p.Kp,
+    BN_HIP(bn::launch_gather_states((h->x_idx && h->d_Xalt[0] ? h->d_Xalt[0] : h->d_X) + (size_t)instance * h->p.Kp * T1 * 3, h->d_idx, h->d_scratch, n, h->p.Kp,
                                     (int)T1, h->stream));
     BN_HIP(hipMemcpyAsync(states_host, h->d_scratch, (size_t)n * T1 * 3 * 4, hipMemcpyDeviceToHost, h->stream));
     BN_HIP(hipStreamSynchronize(h->stream));
@@ -2209,7 +2470,8 @@ int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size
         BN_BIND(h);
         if (int rc = flush_tail(h)) return rc;
     }
-    void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost_out, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal, h->d_ustar};
+    void *ptrs[BN_BUF_COUNT_] = {h->d_X, h->d_w, h->d_cost_out, h->d_U, h->d_ustar, h->d_xstar, h->d_mean, h->d_map, h->d_goal, h->d_ustar,
+                                 h->d_Xalt[0], h->d_Ualt[0]};
     if ((int)id < 0 || id >= BN_BUF_COUNT_) return fail(BN_ERR_INVALID, "unknown buffer id %d", (int)id);
     *device_ptr = ptrs[id];
     if (bytes) *bytes = buffer_bytes(h, id);
@@ -2217,7 +2479,9 @@ int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size
     return BN_OK;
 }
 
-uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves : 0; }
+uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves - (h->hp_armed ? 1 : 0) : 0; }
+int32_t bn_mppi_host_paced(const bn_mppi_t *h) { return h ? (h->hp_enabled ? 1 : 0) : -1; }
+int32_t bn_mppi_states_buffer_index(const bn_mppi_t *h) { return h ? h->x_idx : -1; }
 
 int32_t bn_mppi_arithmetic(const bn_mppi_t *h) { return h ? h->p.ref_order : -1; }
 int32_t bn_mppi_fast_quotient(const bn_mppi_t *h) { return h ? (h->p.pow2 ? 2 : h->p.fast_div) : -1; }

@@ -132,6 +132,13 @@ struct SolveParams {
                          // (bn_mppi_forward_async: the drop-in class's fresh output tensors without a second launch)
     float *out_copy_self;   // ... the same for the tail of THIS launch's solve (self_tail): the aux workgroup of the previous solve's tail
                             // in the same launch must not write the caller's block
+    // ---- host-paced launches (rollout_lat.inc HOSTP; bn_mppi_forward_state_async in a loop) ----
+    int host_paced;                         // this launch's rollouts start from a state the HOST posts after the launch; sv = the previous state
+    const unsigned long long *req_host;     // pinned host memory: kReqGranules {value, tag = solve + 1} granules -- x, y, theta, out pointer lo / hi, command
+    unsigned long long *req_dev;            // device memory: the same granules as the launch's tail workgroup republishes them (the launch's one decision)
+    unsigned long long *spec_status;        // pinned host memory: {2, tag} when the tail workgroup gave up waiting for the host
+    uint32_t req_tag;                       // this launch's request tag (unique per prelaunch: a cancelled launch and its successor never share one)
+    int req_polls;                          // how often the tail workgroup looks for the request before it gives up (~2 us a look)
     int state_inline;    // the (one) instance's state travels in the kernel arguments (sv): a host loop that hands over a fresh state
     float sv[3];         // every control step (bn_mppi_forward_state_async) pays neither an upload nor the prologue's fetch of it
     float *stats;        // (B, 2): max z, sum exp
@@ -162,6 +169,8 @@ size_t lat_lds_bytes(const SolveParams &p);       // 0 when the latency variant 
 int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer for the headline rollout kernel (diagnostics)
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
+hipError_t launch_rollout_lat_host(const SolveParams &p, hipStream_t s);       // the host-paced latency kernel (Philox noise), rollout_lat_host.hip
+hipError_t launch_rollout_lat_host_ref(const SolveParams &p, hipStream_t s);   // ... in the reference's operation order
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
 // K-sharded solve: merge of all shards' partial rows -> ustar_cur, stats_cur, ustar, mean.  group_rows: 64 x (2 + 2T) floats, ticket: one zeroed int
 hipError_t launch_shard_merge(const SolveParams &p, float *group_rows, int *ticket, hipStream_t s);

@@ -1,0 +1,11 @@
+// rollout_lat_host_ref.hip -- the host-paced latency kernel in the REFERENCE's operation order (BN_FLAG_REFERENCE_ORDER); see
+// rollout_lat_host.hip.  Compiled without the SLP vectoriser like the other reference-order units (benchnav_amd/build.py).
+#define BN_ROLE_EPS kEpsPhilox
+#define BN_ROLE_REF true
+#define BN_LAT_HOSTP true
+#include "mppi_device.h"
+#include "rollout_lat.inc"
+
+namespace bn {
+hipError_t launch_rollout_lat_host_ref(const SolveParams &p, hipStream_t s) { return launch_lat_e<kEpsPhilox>(p, s); }
+}  // namespace bn

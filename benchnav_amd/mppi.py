@@ -20,6 +20,16 @@ import torch.nn as nn
 from . import _capi
 
 
+def _raw_stream(dev_index: int) -> int:
+    """hipStream_t of torch's current stream on the device (forward() compares it with the planner's every call)."""
+    return torch._C._cuda_getCurrentRawStream(dev_index)
+
+
+if not hasattr(torch._C, "_cuda_getCurrentRawStream"):          # (a torch without the private accessor: the public one)
+    def _raw_stream(dev_index: int) -> int:                     # noqa: F811
+        return torch.cuda.current_stream(dev_index).cuda_stream
+
+
 class _CallState:
     """Per-call state of MPPI.forward.  A plain object: nn.Module.__setattr__ inspects every assignment (parameters,
     buffers, sub-modules), which costs microseconds per attribute in a loop that runs once per control step."""
@@ -97,6 +107,13 @@ class MPPI(nn.Module):
                       block); False returns views of the planner's buffers (overwritten by the next call).
       lean            do not materialise `_state_seq_batch` (70 % of a solve's HBM bytes): get_top_samples re-rolls the
                       winners on demand and `_state_seq_batch` re-rolls all K rows when it is read, bit-identical either way.
+      host_loop       opt-in for the loop of test_mppi.py:174-181 -- one forward(state) per control step with a CPU `state`, the host
+                      consuming `first_action()` -- with noise="philox": every forward() also enqueues the NEXT solve's launch, which gets
+                      its launch latency, noise, mean and window behind it while the host is busy and then waits on the device for the
+                      state the next forward() hands over (25 -> ~14 us per control step).  Outputs stay stream-ordered.  A launch
+                      that waits is cancelled by any other library call of the planner (`release()` is the cheapest) and gives up by itself
+                      after ~50 ms (the next forward() then starts over with an ordinary launch); a device-wide
+                      `torch.cuda.synchronize()` issued while it waits blocks that long -- call `release()` first.
       reference_order the transit in the reference's own operation order (robot_model.py:86-88: sin / cos of every step's
                       heading, x + ((trav v) cos) dt): no cell flips against the reference beyond what libm vs SLEEF gives
                       (DESIGN.md 5), on the same kernels (one launch per solve) at ~1.4x the single-instance latency -- the chain's extra
@@ -112,7 +129,7 @@ class MPPI(nn.Module):
                  sigmas: torch.Tensor, lambda_: float, device=torch.device("cuda"), dtype=torch.float32,
                  seed: int = 42, *, noise: str = "torch_device", store_controls: bool = True,
                  copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1, sampled_slip: bool = False,
-                 lean: bool = False, reference_order: bool = False) -> None:
+                 lean: bool = False, reference_order: bool = False, host_loop: bool = False) -> None:
         super().__init__()
         torch.manual_seed(seed)                                    # mppi.py:55
 
@@ -171,11 +188,13 @@ class MPPI(nn.Module):
         cfg.seed = seed
         cfg.flags = ((_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0) | (_capi.BN_FLAG_PROFILE if profile else 0)
                      | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0) | (_capi.BN_FLAG_LEAN if lean else 0)
-                     | (_capi.BN_FLAG_REFERENCE_ORDER if reference_order else 0))
+                     | (_capi.BN_FLAG_REFERENCE_ORDER if reference_order else 0)
+                     | (_capi.BN_FLAG_HOST_PACED if (host_loop and noise == "philox") else 0))
         self._lean = bool(lean)
         with torch.cuda.device(dev):
             self._stream = torch.cuda.current_stream(dev)
             cfg.stream = self._stream.cuda_stream
+            self._stream_id, self._dev_index = self._stream.cuda_stream, dev.index
             self._handle = C.c_void_p()
             _capi.check(lib.bn_mppi_create(C.byref(cfg), C.byref(self._handle)))
         self._lib = lib
@@ -192,9 +211,13 @@ class MPPI(nn.Module):
         K, T = num_samples, horizon
         Kp = int(lib.bn_mppi_row_pitch(self._handle))        # rows are pitched to 64*ceil(K/64) floats
         self._buf_X = None if lean else self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, Kp))[:, :, :K]
+        self._host_loop = int(lib.bn_mppi_host_paced(self._handle)) == 1
+        # host-paced solves alternate between two trajectory / control buffers (two launches in flight): bn_mppi_states_buffer_index
+        self.__dict__["_buf_X_alt"] = self._wrap(_capi.BN_BUF_STATES_ALT, (T + 1, 3, Kp))[:, :, :K] if (self._host_loop and not lean) else None
         self._buf_w = self._wrap(_capi.BN_BUF_WEIGHTS, (K,))
         self._buf_cost = self._wrap(_capi.BN_BUF_COSTS, (K,))
         self._buf_U = self._wrap(_capi.BN_BUF_CONTROLS, (T, 2, Kp))[:, :, :K] if store_controls else None
+        self.__dict__["_buf_U_alt"] = self._wrap(_capi.BN_BUF_CONTROLS_ALT, (T, 2, Kp))[:, :, :K] if (self._host_loop and store_controls) else None
         self._buf_out = self._wrap(_capi.BN_BUF_USTAR_XSTAR, (T * 2 + (T + 1) * 3,))     # U* | X*, one block
         self._buf_ustar = self._buf_out[:T * 2].view(T, 2)
         self._buf_xstar = self._buf_out[T * 2:].view(1, T + 1, 3)
@@ -269,7 +292,14 @@ class MPPI(nn.Module):
             if self._cs.rolled is None:
                 self._cs.rolled = self._reroll(None, self._num_samples)
             return self._cs.rolled
+        if self._host_loop and self._lib.bn_mppi_states_buffer_index(self._h) == 1:
+            return self._buf_X_alt.permute(2, 0, 1)
         return self._buf_X.permute(2, 0, 1)
+
+    def release(self) -> None:
+        """End a `host_loop` loop: cancels the launch that waits on the device for the next state (a word in pinned memory, no
+        synchronisation) and enqueues anything pending.  Every other method of the planner but forward() / first_action() does the same."""
+        _capi.check(self._lib.bn_mppi_flush(self._handle))
 
     def _reroll(self, idx: Optional[torch.Tensor], n: int) -> torch.Tensor:
         out = torch.empty(n, self._horizon + 1, 3, device=self._device, dtype=self._dtype)
@@ -289,6 +319,8 @@ class MPPI(nn.Module):
     def _perturbed_action_seqs(self) -> torch.Tensor:
         if self._buf_U is None:
             raise AttributeError("_perturbed_action_seqs is not stored (store_controls=False)")
+        if self._host_loop and self._lib.bn_mppi_states_buffer_index(self._h) == 1:
+            return self._buf_U_alt.permute(2, 0, 1)
         return self._buf_U.permute(2, 0, 1)
 
     # -- the solve ---------------------------------------------------------------------
@@ -312,6 +344,23 @@ class MPPI(nn.Module):
     def _on_planner_stream(self):
         return MPPI._Fence(self)
 
+    _OUT_POOL = 32      # fresh output tensors are carved from blocks of this many (one torch.empty per 32 forwards)
+
+    def _new_out_block(self):
+        """Fresh (U*, X*) tensors for the next _OUT_POOL forwards: ONE allocation, views made in bulk (the reference returns new tensors
+        from every forward(); a torch.empty and two as_strided per call were 5 of the drop-in step's microseconds)."""
+        n, T, no = self._OUT_POOL, self._horizon, self._n_out
+        if self._host_loop:
+            # host-loop launches run on a stream of the library's own: the block torch's allocator hands out next may have been freed
+            # with reads still queued on torch's stream -- ordered for work on THAT stream, not for ours.  Once per _OUT_POOL forwards.
+            torch.cuda.current_stream(self._device).synchronize()
+        blk = torch.empty(n, no, device=self._device, dtype=self._dtype)
+        d = self.__dict__
+        d["_out_U"] = blk[:, :2 * T].view(n, T, 2)
+        d["_out_X"] = blk[:, 2 * T:].view(n, 1, T + 1, 3)
+        d["_out_ptr"] = blk.data_ptr()
+        d["_out_i"] = 0
+
     def forward(self, state: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Solve the optimal control problem (mppi.py:130-219).
 
@@ -322,7 +371,7 @@ class MPPI(nn.Module):
             state = torch.tensor(state, dtype=self._dtype)
         assert state.shape == (self._dim_state,)
         fwd = self._fwd
-        if state.device.type == "cpu":
+        if state.is_cpu:
             # a host loop's state (the reference moves it, mppi.py:140-144): taken by value at the call -- no upload, no device tensor
             if state.dtype != self._dtype or not state.is_contiguous():
                 state = state.detach().to(self._dtype).contiguous()
@@ -342,19 +391,26 @@ class MPPI(nn.Module):
         cs = self._cs
         cs.eps, cs.noise_cache, cs.rolled = eps, None, None           # _action_noises and lean rows are derived on demand
         cs.state = state                                               # keep alive until the kernels ran
-        # fresh output tensors like the reference's: the tail writes its packed U* | X* block into `out` as well (no extra launch)
-        out = torch.empty(self._n_out, device=self._device, dtype=self._dtype) if self._copy_outputs else None
-        optr = None if out is None else out.data_ptr()
-        if torch.cuda.current_stream(self._device).cuda_stream == self._stream.cuda_stream:
+        # fresh output tensors like the reference's: the tail writes its packed U* | X* block into the caller's block as well (no extra launch)
+        d = self.__dict__
+        i = -1
+        optr = None
+        if self._copy_outputs:
+            i = d.get("_out_i", self._OUT_POOL)
+            if i >= self._OUT_POOL:
+                self._new_out_block()
+                i = 0
+            d["_out_i"] = i + 1
+            optr = d["_out_ptr"] + i * self._n_out * 4
+        if _raw_stream(self._dev_index) == self._stream_id:
             rc = fwd(self._h, state.data_ptr(), eptr, kind, optr)   # solve + tail: U*, X*, weights of THIS solve, stream-ordered
         else:
             with self._on_planner_stream():
                 rc = fwd(self._h, state.data_ptr(), eptr, kind, optr)
         if rc:
             _capi.check(rc)
-        if out is not None:
-            T = self._horizon
-            return out.as_strided((T, 2), (2, 1), 0), out.as_strided((1, T + 1, 3), (3 * (T + 1), 3, 1), 2 * T)
+        if i >= 0:
+            return d["_out_U"][i], d["_out_X"][i]
         return self._buf_ustar, self._buf_xstar
 
     solve = forward

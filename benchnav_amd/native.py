@@ -32,7 +32,7 @@ class NativeMPPI:
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
                  profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False, kernel: str = "auto",
-                 lean: bool = False, overlap: bool = True, reference_order: bool = False):
+                 lean: bool = False, overlap: bool = True, reference_order: bool = False, host_paced: bool = False):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -63,6 +63,7 @@ class NativeMPPI:
                      | (_capi.BN_FLAG_LEAN if lean else 0)
                      | (0 if overlap else _capi.BN_FLAG_NO_OVERLAP)
                      | (_capi.BN_FLAG_REFERENCE_ORDER if reference_order else 0)
+                     | (_capi.BN_FLAG_HOST_PACED if host_paced else 0)
                      | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL, "lat": _capi.BN_FLAG_LAT_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
@@ -158,6 +159,13 @@ class NativeMPPI:
         """... with the (B,3) states taken from the host by value at the call (no upload is enqueued for one instance on the latency kernel)."""
         st = _f32(states).reshape(self.B, 3)
         _capi.check(self._lib.bn_mppi_forward_state_async(self._h, C.c_void_p(st.ctypes.data), C.c_void_p(eps_ptr), kind, C.c_void_p(out_ptr)))
+
+    def host_paced(self) -> bool:
+        """BN_FLAG_HOST_PACED was given and the handle qualifies: forward_state_async enqueues the next solve's launch one step ahead."""
+        return int(self._lib.bn_mppi_host_paced(self._h)) == 1
+
+    def states_buffer_index(self) -> int:
+        return int(self._lib.bn_mppi_states_buffer_index(self._h))
 
     def launches_per_forward(self) -> int:
         return int(self._lib.bn_mppi_launches_per_forward(self._h))

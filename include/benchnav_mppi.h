@@ -64,7 +64,9 @@ typedef enum bn_buffer_id {
     BN_BUF_GOAL = 8,      /* (B,2)                                                             */
     BN_BUF_USTAR_XSTAR = 9, /* the (B,T,2) U* block followed by the (B,T+1,3) X* block: both outputs of forward() are one
                                contiguous allocation, so a caller that wants private copies makes ONE device copy     */
-    BN_BUF_COUNT_ = 10
+    BN_BUF_STATES_ALT = 10,   /* the second (B,T+1,3,Kp) / (B,T,2,Kp) buffers of handles that overlap launches (bn_mppi_states_buffer_index) */
+    BN_BUF_CONTROLS_ALT = 11,
+    BN_BUF_COUNT_ = 12
 } bn_buffer_id;
 
 enum {
@@ -85,6 +87,10 @@ enum {
                                           regenerate the requested rows of the latest solve bit-identically on demand */
     BN_FLAG_SAMPLED_SLIP = 1u << 6,    /* BASELINE config 3: every traversability lookup of the rollouts draws
                                           slip ~ Normal(map, slip_std)[cell]; see bn_mppi_set_slip_std */
+    BN_FLAG_HOST_PACED = 1u << 13,     /* opt-in for a host loop that calls bn_mppi_forward_state_async once per control step and consumes every solve's
+                                          first action (test_mppi.py:174-181): the launch of the NEXT solve is enqueued one step ahead and waits on
+                                          the device for the state the next call posts -- see bn_mppi_forward_state_async.  One instance, latency
+                                          kernel, num_samples <= 1024, Philox noise; bn_mppi_host_paced() tells whether the handle qualifies */
     BN_FLAG_REFERENCE_ORDER = 1u << 12 /* the transit in the REFERENCE's own operation order, robot_model.py:75-95: sin / cos of every
                                           step's heading, x + ((trav v) cos) dt, theta + (trav omega) dt, the general heading wrap.
                                           The default arithmetic (heading vector carried by a rotation per step, one fused update) leaves
@@ -200,6 +206,28 @@ int bn_mppi_forward_async(bn_mppi_t *h, const float *states_device, const float 
  * keeps to two launches from then on. */
 int bn_mppi_forward_state_async(bn_mppi_t *h, const float *states_host, const float *eps_device, bn_noise_kind noise,
                                 float *out_device);
+/* With BN_FLAG_HOST_PACED (and BN_NOISE_PHILOX) the call also enqueues the launch of the NEXT solve -- on a stream of the library's
+ * own -- before it returns: while the host waits for this solve's first action, takes its environment step and comes back, that
+ * launch gets its latency, its instruction fetch, the horizon's noise, its mean (the merge of this solve's partial rows), the whole
+ * control tile and a window around THIS state (two cells wider each side) behind it and then waits, on the device, for the state the
+ * next call posts to pinned host memory.  Between the host's store and the first action's way back only the rollouts' 50-step chain,
+ * the cost epilogue and the merge are left: 25 -> ~14 us per control step at K = 1024, T = 50.  Results are bit-identical to the
+ * one-launch path's (same noise stream positions, same merges).
+ *   - outputs stay stream-ordered for what comes AFTER: every posted solve's launch is followed by an event the handle's stream waits
+ *     for.  What was enqueued on the handle's stream BEFORE the call is not waited for (the launch is paced by the host's store, not by
+ *     the queue): work left there that still reads the planner's own buffers (BN_BUF_WEIGHTS, BN_BUF_STATES, BN_BUF_USTAR_XSTAR ...),
+ *     or that still uses the memory `out_device` was carved from, must have completed -- fresh output blocks per call need nothing;
+ *   - a launch that waits for a state holds 17 CUs and is cancelled -- a word in pinned memory, no synchronisation -- by every other
+ *     entry point of the handle except bn_mppi_first_action and the pure queries (the next bn_mppi_forward_state_async then pays one
+ *     ordinary launch); left alone it gives up after ~50 ms and the next call starts over the same way;
+ *   - a DEVICE-WIDE synchronisation (hipDeviceSynchronize, torch.cuda.synchronize) issued while a launch waits blocks for up to
+ *     those 50 ms: end the loop with any other call of the handle (bn_mppi_flush is the cheapest) first.  This is why the mode is
+ *     opt-in;
+ *   - a state more than two cells from the previous one (a reset) is handled inside the waiting launch (it stages its window again). */
+int32_t bn_mppi_host_paced(const bn_mppi_t *h);      /* 1: BN_FLAG_HOST_PACED was given and the handle qualifies */
+/* Which of the two trajectory / control buffers holds the LATEST solve (0: BN_BUF_STATES / BN_BUF_CONTROLS, 1: the *_ALT ones): host-paced
+ * solves alternate between them (two launches are in flight and must not write the same addresses); every other path writes buffer 0. */
+int32_t bn_mppi_states_buffer_index(const bn_mppi_t *h);
 /* n dependent solves enqueued from one call (the warm start chains them on the device; the state is
  * re-read from `states` by every solve).  Noise block i is eps + (i % eps_ring) * eps_stride floats.
  * With n >= 3 (and device-resident inputs) the solves of one call alternate between the handle's stream and an internal one and
@@ -354,6 +382,9 @@ uint64_t bn_mppi_recovery_count(const bn_mppi_t *h);
  * overwrites what those batches wrote (mean, U* | X*, weights, costs, trajectories) with NaN patterns.  The next synchronising
  * call re-runs them on one stream. */
 int bn_mppi_debug_expire_wait(bn_mppi_t *h);
+/* Test hook (BN_FLAG_HOST_PACED): how many looks of ~2 us a prelaunched solve waits for its state before it gives up (default 25000), and
+ * whether bn_mppi_forward_state_async posts the state without checking that the launch is still waiting. */
+int bn_mppi_debug_host_paced(bn_mppi_t *h, int32_t polls, int32_t post_unchecked);
 /* Enqueue the pending tail (if any) without waiting.  An expiry that has already been flagged is repaired here (that does wait). */
 int bn_mppi_flush(bn_mppi_t *h);
 

@@ -9,14 +9,14 @@ torch.set_num_threads(1)
 fx = load_case("c2")
 import sys as _sys
 quick = "--quick" in _sys.argv
-combos = ((("philox", True, False, "cpu"), ("philox", True, False, "cuda"), ("philox", False, False, "cpu")) if quick else
+combos = ((("philox", True, False, "cpu"), ("philox", True, False, "loop"), ("philox", False, False, "loop")) if quick else
           (("torch", True, False, "cuda"), ("torch_device", True, False, "cuda"), ("philox", True, False, "cuda"), ("philox", True, False, "cpu"),
-           ("philox", False, False, "cuda"), ("philox", False, False, "cpu"), ("philox", False, True, "cpu")))
+           ("philox", False, False, "cuda"), ("philox", False, False, "cpu"), ("philox", False, True, "cpu"), ("philox", True, False, "loop"), ("philox", False, False, "loop")))
 for mode, copy, lean, where in combos:
-    solver = mppi_for_fixture(fx, noise=mode, copy_outputs=copy, store_controls=False, lean=lean)
-    state = torch.tensor(fx["state_0"], device=where)      # "cpu": the host loop's state, taken by value (bn_mppi_forward_state_async)
+    solver = mppi_for_fixture(fx, noise=mode, copy_outputs=copy, store_controls=False, lean=lean, host_loop=(where == "loop"))      # "loop": MPPI(host_loop=True), CPU state
+    state = torch.tensor(fx["state_0"], device="cpu" if where == "loop" else where)      # "cpu": the host loop's state, taken by value (bn_mppi_forward_state_async)
     for _ in range(50): U, X = solver(state)
-    torch.cuda.synchronize(); n = 500
+    solver.release(); torch.cuda.synchronize(); n = 500
     host = 0.0
     t = time.perf_counter()
     for _ in range(n):
@@ -25,17 +25,19 @@ for mode, copy, lean, where in combos:
         host += time.perf_counter() - t0
         a = U[0].cpu()                      # the reference loop reads action_seq[0] every step
     dt = (time.perf_counter() - t) / n
+    solver.release()
     # the same step with the first action taken from the tail's host mailbox (MPPI.first_action): no synchronisation, no copy
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n):
         U, X = solver(state)
         a = solver.first_action()
     dm = (time.perf_counter() - t) / n
+    solver.release()
     assert torch.equal(a, U[0].cpu())
     a = a.clone()
     # back-to-back forwards without a read-back: the rate the host can feed the GPU at
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): U, X = solver(state)
-    torch.cuda.synchronize(); dq = (time.perf_counter() - t) / n
+    solver.release(); torch.cuda.synchronize(); dq = (time.perf_counter() - t) / n
     print(f"noise={mode:12s} copy_outputs={copy!s:5s} lean={lean!s:5s} state={where:4s}: forward() host {host / n * 1e6:6.1f} us | forward()+readback {dt * 1e6:6.1f} us "
           f"({1 / dt:.0f} Hz) | forward()+first_action() {dm * 1e6:6.1f} us ({1 / dm:.0f} Hz) | back-to-back {dq * 1e6:6.1f} us", flush=True)

@@ -10,7 +10,9 @@ b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ.get
 from benchnav_amd import NativeMPPI, synth, _capi
 inst = synth.make_instance(256, seed=0)
 ref = os.environ.get("BN_REF") == "1"
-pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, stream=0, reference_order=ref)
+paced = os.environ.get("BN_PACED") == "1"
+pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, stream=0, reference_order=ref, host_paced=paced)
+assert pl.host_paced() == paced
 pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
 stamps = torch.zeros(1024, dtype=torch.int64, device="cuda")
 lib = pl._lib
@@ -27,12 +29,19 @@ h = pl._h
 torch.cuda.synchronize()
 for _ in range(200):
     fwd(h, sptr, None, 0, None); lib.bn_mppi_first_action(h, 0, fap)
-rows, host = [], []
+rows, host, pars = [], [], []
 for rep in range(60):
-    torch.cuda.synchronize()
+    if paced:
+        for _ in range(3):
+            fwd(h, sptr, None, 0, None); lib.bn_mppi_first_action(h, 0, fap)      # steady state: the launch of the step timed below is waiting
+        time.sleep(20e-6)
+    else:
+        torch.cuda.synchronize()
     t0 = time.perf_counter(); fwd(h, sptr, None, 0, None); t1 = time.perf_counter(); lib.bn_mppi_first_action(h, 0, fap); t2 = time.perf_counter()
+    if paced: lib.bn_mppi_flush(h)
     torch.cuda.synchronize(); t3 = time.perf_counter()
     host.append((t1 - t0, t2 - t1, t3 - t2))
+    pars.append(int(pl.solve_count() - 1) & 1)
     rows.append(stamps.cpu().numpy().astype(np.float64).copy())
 host = np.median(np.array(host), axis=0) * 1e6
 # a loop without synchronisation: the rate the drop-in boundary runs at
@@ -41,19 +50,17 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(n):
     fwd(h, sptr, None, 0, None); lib.bn_mppi_first_action(h, 0, fap)
 loop = (time.perf_counter() - t) / n * 1e6
+lib.bn_mppi_flush(h)
 torch.cuda.synchronize()
 R = np.stack(rows)
-par = int(pl.solve_count() - 1) & 1          # (every launch writes its parity's slots; with one launch per step both parities are fresh)
-w = lambda r, slot: min(r[32 + slot], r[48 + slot]) if False else None
-def wall(r, slot):
-    a, c = r[32 + slot], r[48 + slot]
-    return max(a, c)                          # the later of the two parities = the latest launch
 rel = []
-for r in R:
-    t0w = wall(r, 0)
-    rel.append([ (wall(r, s) - t0w) / 100.0 for s in (1, 14, 2, 3, 9, 4, 5) ] + [ (r[900 + i] - t0w) / 100.0 for i in range(7) ])
+for r, par in zip(R, pars):
+    base = 32 + 16 * par
+    t0w = r[base + 13] if paced else r[base + 0]          # paced: the moment the rollout workgroup saw "go"; else its start
+    rel.append([(r[base + s_] - t0w) / 100.0 for s_ in (0, 14, 1, 2, 3, 4, 5)] + [(r[900 + 16 * par + i] - t0w) / 100.0 for i in range(7)] + [(r[910 + 4 * par] - t0w) / 100.0])
 rel = np.median(np.array(rel), axis=0)
-print(f"host: forward call {host[0]:.1f} us | first_action wait {host[1]:.1f} us | rest of the kernel (sync) {host[2]:.1f} us | loop forward+first_action {loop:.2f} us/step  (state={'cuda' if dev_state else 'host by value'}, ref_order={ref})")
-print("rollout wg(0,0), us after its start: prologue end %.2f | mean+window in LDS %.2f | chunk0 %.2f | chain end %.2f | costs %.2f | after barrier %.2f | column sums out %.2f" % tuple(rel[:7]))
-print("self tail, us after the rollout wg's start: enter %.2f | window staged %.2f | rows seen %.2f | merged + mailbox %.2f | X* rolled %.2f | all waves %.2f | end %.2f" % tuple(rel[7:]))
+print(f"host: forward call {host[0]:.1f} us | first_action wait {host[1]:.1f} us | rest of the kernel (sync) {host[2]:.1f} us | loop forward+first_action {loop:.2f} us/step  (state={'cuda' if dev_state else 'host by value'}, ref_order={ref}, host_paced={paced})")
+ref0 = "the rollout wg saw go" if paced else "the rollout wg's start"
+print("rollout wg(0,0), us after %s: start %.2f | ready, polls for the request %.2f | prologue end %.2f | chunk0 %.2f | chain end %.2f | after barrier %.2f | column sums out %.2f" % ((ref0,) + tuple(rel[:7])))
+print("self tail, us after %s: enter %.2f | window staged %.2f | rows seen %.2f | merged + mailbox %.2f | X* rolled %.2f | all waves %.2f | end %.2f | (paced) request taken from the host %.2f" % ((ref0,) + tuple(rel[7:])))
 pl.close()
