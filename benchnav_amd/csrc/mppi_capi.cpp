@@ -20,6 +20,8 @@
 #include <sys/file.h>
 #include <unistd.h>
 #include <dlfcn.h>
+#include <hsa/hsa.h>        // types only (as RCCL below): the HSA runtime HIP itself runs on is looked up at run time, and only by a host-paced handle
+#include <hsa/hsa_ext_amd.h>
 #include <rccl/rccl.h>      // types only: the library itself is opened at run time (rccl_api), and only by a K-sharded solve
 #include <map>
 #include <mutex>
@@ -220,6 +222,7 @@ struct bn_mppi {
     hipStream_t hp_stream[2] = {};   // [0] = xstream[0], [1] = xstream[1] (created for this mode); the launches alternate
     hipEvent_t hp_ev[2] = {};        // recorded behind every prelaunch; the handle's stream waits for it when the request is posted
     unsigned long long *h_req = nullptr, *d_req = nullptr;         // pinned: kSlots x 8 request granules + (at [kSlots * 8]) the give-up word
+    unsigned long long *req_bar = nullptr;                         // the request granules in DEVICE memory the host writes through the BAR (bar_alloc), or null
     unsigned long long *d_req_dev = nullptr;                       // device: kSlots x 8, republished by the launches' tail workgroups
     uint32_t hp_seq = 0;             // request tags, unique per prelaunch
     bool hp_armed = false;           // a prelaunched solve waits for its state
@@ -234,6 +237,7 @@ struct bn_mppi {
     int hp_extra = 2;                // cells the speculative window is wider on each side
     int x_idx = 0;                   // which trajectory / control buffer holds the latest solve (bn_mppi_states_buffer_index)
     int hp_next_q = 0;
+    std::chrono::steady_clock::time_point hp_armed_at{};      // when the waiting launch was enqueued (a request is posted only well within its patience)
     int hp_polls = 25000;            // how long a prelaunched solve waits for its state: looks of ~2 us each (~50 ms); bn_mppi_debug_host_paced
     bool lat_kernel = false;         // plain pipelined solves of a launch that leaves every workgroup a CU: rollout_lat_kernel
     bool wave_kernel = false;        // plain pipelined solves use rollout_wave_kernel (episodes keep the role kernel)
@@ -323,18 +327,113 @@ int ensure_scratch(bn_mppi *h, size_t bytes)
 
 int guard_foreign_overlap(bn_mppi *h);      // (defined with order_behind_foreign_overlap)
 
+// ---- host-paced loop: request words the HOST writes straight into device memory ---------------------------------------------------
+// The waiting launch polls its request.  Pinned host memory makes every look a PCIe read round trip (~3 us on this platform: the
+// state was seen ~4 us after the host's store, a quarter of the control step).  Device memory the CPU can write -- a fine-grained VRAM
+// allocation of the HSA runtime HIP itself runs on, opened to the CPU agent: stores go out through the PCIe BAR as posted writes --
+// turns that around: the host's store travels once, the GPU polls its own memory.  No such allocation (no large BAR, an HSA runtime
+// without the entry points, an agent that cannot be matched to the HIP device): the words stay in pinned host memory, as before.
+struct HsaApi {
+    void *lib = nullptr;
+    decltype(&hsa_iterate_agents) iterate_agents = nullptr;
+    decltype(&hsa_agent_get_info) agent_get_info = nullptr;
+    decltype(&hsa_amd_agent_iterate_memory_pools) iterate_pools = nullptr;
+    decltype(&hsa_amd_memory_pool_get_info) pool_get_info = nullptr;
+    decltype(&hsa_amd_memory_pool_allocate) pool_allocate = nullptr;
+    decltype(&hsa_amd_memory_pool_free) pool_free = nullptr;
+    decltype(&hsa_amd_agents_allow_access) allow_access = nullptr;
+};
+const HsaApi *hsa_api()
+{
+    static const HsaApi api = [] {
+        HsaApi a;
+        for (const char *name : {"libhsa-runtime64.so.1", "libhsa-runtime64.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);      // the copy HIP has loaded, or none
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        a.iterate_agents = reinterpret_cast<decltype(a.iterate_agents)>(dlsym(a.lib, "hsa_iterate_agents"));
+        a.agent_get_info = reinterpret_cast<decltype(a.agent_get_info)>(dlsym(a.lib, "hsa_agent_get_info"));
+        a.iterate_pools = reinterpret_cast<decltype(a.iterate_pools)>(dlsym(a.lib, "hsa_amd_agent_iterate_memory_pools"));
+        a.pool_get_info = reinterpret_cast<decltype(a.pool_get_info)>(dlsym(a.lib, "hsa_amd_memory_pool_get_info"));
+        a.pool_allocate = reinterpret_cast<decltype(a.pool_allocate)>(dlsym(a.lib, "hsa_amd_memory_pool_allocate"));
+        a.pool_free = reinterpret_cast<decltype(a.pool_free)>(dlsym(a.lib, "hsa_amd_memory_pool_free"));
+        a.allow_access = reinterpret_cast<decltype(a.allow_access)>(dlsym(a.lib, "hsa_amd_agents_allow_access"));
+        if (!a.iterate_agents || !a.agent_get_info || !a.iterate_pools || !a.pool_get_info || !a.pool_allocate || !a.pool_free || !a.allow_access) a.lib = nullptr;
+        return a;
+    }();
+    return api.lib ? &api : nullptr;
+}
+
+struct BarFind { const HsaApi *api; uint32_t bdf, domain; hsa_agent_t gpu{}, cpu{}; bool have_gpu = false, have_cpu = false; hsa_amd_memory_pool_t pool{}; int pool_rank = 0; };
+
+hsa_status_t bar_agent_cb(hsa_agent_t agent, void *data)
+{
+    BarFind *f = static_cast<BarFind *>(data);
+    hsa_device_type_t type;
+    if (f->api->agent_get_info(agent, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (type == HSA_DEVICE_TYPE_CPU) { if (!f->have_cpu) { f->cpu = agent; f->have_cpu = true; } return HSA_STATUS_SUCCESS; }
+    if (type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0, dom = 0;
+    if (f->api->agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    (void)f->api->agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
+    if (bdf == f->bdf && dom == f->domain) { f->gpu = agent; f->have_gpu = true; }
+    return HSA_STATUS_SUCCESS;
+}
+
+hsa_status_t bar_pool_cb(hsa_amd_memory_pool_t pool, void *data)
+{
+    BarFind *f = static_cast<BarFind *>(data);
+    hsa_amd_segment_t seg;
+    uint32_t flags = 0;
+    bool alloc = false;
+    if (f->api->pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+    if (f->api->pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc) != HSA_STATUS_SUCCESS || !alloc) return HSA_STATUS_SUCCESS;
+    (void)f->api->pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    // fine-grained first (coherent with the host by construction), then the extended-scope kind; never the coarse-grained pool
+    const int rank = (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_FINE_GRAINED) ? 2 : (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_EXTENDED_SCOPE_FINE_GRAINED) ? 1 : 0;
+    if (rank > f->pool_rank) { f->pool = pool; f->pool_rank = rank; }
+    return HSA_STATUS_SUCCESS;
+}
+
+// `bytes` of device memory the CPU may write; nullptr when the platform does not offer it.
+void *bar_alloc(int device_id, size_t bytes)
+{
+    const HsaApi *a = hsa_api();
+    if (!a) return nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    BarFind f;
+    f.api = a;
+    f.bdf = ((uint32_t)prop.pciBusID << 8) | ((uint32_t)prop.pciDeviceID << 3);
+    f.domain = (uint32_t)prop.pciDomainID;
+    if (a->iterate_agents(bar_agent_cb, &f) != HSA_STATUS_SUCCESS || !f.have_gpu || !f.have_cpu) return nullptr;
+    if (a->iterate_pools(f.gpu, bar_pool_cb, &f) != HSA_STATUS_SUCCESS || f.pool_rank == 0) return nullptr;
+    void *ptr = nullptr;
+    if (a->pool_allocate(f.pool, (bytes + 4095) & ~(size_t)4095, 0, &ptr) != HSA_STATUS_SUCCESS || !ptr) return nullptr;
+    if (a->allow_access(1, &f.cpu, nullptr, ptr) != HSA_STATUS_SUCCESS) { (void)a->pool_free(ptr); return nullptr; }
+    return ptr;
+}
+
+void bar_free(void *ptr)
+{
+    if (!ptr) return;
+    if (const HsaApi *a = hsa_api()) (void)a->pool_free(ptr);
+}
+
 // ---- host-paced loop: the request words --------------------------------------------------------------------------------------
 // A request is six {value, tag} granules in pinned memory (x, y, theta, the caller's output block lo / hi, the command); the
 // launch's tail workgroup takes them when all six carry the launch's tag.  Plain 8-byte stores: x86 keeps them in order, and each
 // granule vouches for itself anyway.
 void hp_write_request(bn_mppi *h, int slot, uint32_t tag, const float st[3], const float *out, uint32_t cmd)
 {
-    unsigned long long *r = h->h_req + (size_t)slot * 8;
+    unsigned long long *r = (h->req_bar ? h->req_bar : h->h_req) + (size_t)slot * 8;
     uint32_t w[6] = {0, 0, 0, 0, 0, cmd};
     if (st) std::memcpy(w, st, 12);
     const unsigned long long o = (unsigned long long)(uintptr_t)out;
     w[3] = (uint32_t)o; w[4] = (uint32_t)(o >> 32);
     for (int i = 0; i < 6; ++i) __atomic_store_n(r + i, ((unsigned long long)tag << 32) | w[i], __ATOMIC_RELEASE);
+    if (h->req_bar) __builtin_ia32_sfence();           // device memory through the BAR is write-combining: out with it now
 }
 
 // The tail workgroup of the launch with this tag gave up waiting for the host (~50 ms) and said so: the launch has ended, nothing happened.
@@ -923,6 +1022,24 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
             if (ok && rc == BN_OK) {
                 h->hp_stream[0] = h->xstream[0]; h->hp_stream[1] = h->xstream[1];
                 h->hp_enabled = true;
+                // request words in device memory the host can write (see bar_alloc) -- taken only if a kernel reads back what the CPU wrote
+                if (!std::getenv("BENCHNAV_NO_BAR_REQUEST")) {
+                    unsigned long long *bar = static_cast<unsigned long long *>(bar_alloc(cfg->device_id, words * sizeof(unsigned long long)));
+                    if (bar) {
+                        bool good = true;
+                        for (size_t i = 0; i < words; ++i) bar[i] = 0;
+                        const unsigned long long magic = 0x5a5a0000c3c30001ull;
+                        __atomic_store_n(bar + 3, magic, __ATOMIC_RELEASE);
+                        __builtin_ia32_sfence();
+                        good = bn::launch_echo64(bar + 3, h->d_req + (size_t)kSlots * 8 + 7, h->xstream[0]) == hipSuccess && hipStreamSynchronize(h->xstream[0]) == hipSuccess &&
+                               __atomic_load_n(h->h_req + (size_t)kSlots * 8 + 7, __ATOMIC_ACQUIRE) == magic;
+                        (void)hipGetLastError();
+                        __atomic_store_n(bar + 3, 0ull, __ATOMIC_RELEASE);
+                        __builtin_ia32_sfence();
+                        h->h_req[(size_t)kSlots * 8 + 7] = 0;
+                        if (good) h->req_bar = bar; else bar_free(bar);
+                    }
+                }
             }
         }
         (void)hipGetLastError();                       // (a handle that cannot pace keeps the one-launch path: bn_mppi_host_paced() tells)
@@ -985,6 +1102,7 @@ void bn_mppi_destroy(bn_mppi_t *h)
     if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->h_mail) (void)hipHostFree(h->h_mail);
     if (h->h_req) (void)hipHostFree(h->h_req);
+    if (h->req_bar) bar_free(h->req_bar);
     if (h->d_req_dev) (void)hipFree(h->d_req_dev);
     for (hipEvent_t e : h->hp_ev) if (e) (void)hipEventDestroy(e);
     if (h->d_mean_snap) (void)hipFree(h->d_mean_snap);
@@ -1373,6 +1491,22 @@ int bn_mppi_solve_async(bn_mppi_t *h, const float *states, bn_mem_kind states_wh
     return solve_impl(h, states, states_where, eps, noise, false);
 }
 
+#ifdef BN_TIMING
+// host-side split of the host-paced forward (tools/stamps_forward.py prints it at exit): nanoseconds and calls per piece
+struct HpClock { const char *name; long long ns = 0, n = 0; };
+static HpClock g_hpc[6] = {{"post: request words"}, {"post: hipStreamWaitEvent"}, {"prelaunch: checks + ack"}, {"prelaunch: kernel launch"}, {"prelaunch: hipEventRecord"}, {"self_check + bind"}};
+struct HpTick { int i; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                explicit HpTick(int i_) : i(i_) {}
+                ~HpTick() { g_hpc[i].ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_hpc[i].n += 1; } };
+#define BN_HP_TICK(i) HpTick bn_hp_tick_##i(i)
+extern "C" void bn_mppi_debug_hp_clock(void)
+{
+    for (const HpClock &c : g_hpc) if (c.n) std::fprintf(stderr, "[hp host] %-28s %7.2f us x %lld\n", c.name, c.ns / 1e3 / c.n, c.n);
+}
+#else
+#define BN_HP_TICK(i) do { } while (0)
+#endif
+
 // Host-paced loop: enqueue the launch of the solve AFTER the latest one, on a private stream; it waits on the device for its state.
 // Best effort: returns false (and leaves nothing behind) when the handle's state does not allow it.
 static bool hp_prelaunch(bn_mppi *h)
@@ -1380,6 +1514,7 @@ static bool hp_prelaunch(bn_mppi *h)
     if (!h->hp_enabled || h->hp_armed || h->self_off || !h->hp_gran_valid || h->tail_pending || h->shard_pending || h->in_episode || h->replaying ||
         !h->map_set || !h->goal_set || h->solves == 0)
         return false;
+    std::chrono::steady_clock::time_point bn_t_pre = std::chrono::steady_clock::now(); (void)bn_t_pre;
     {   // not beside another handle's launches (the latency kernel is sized for a device it has to itself: see g_handles)
         std::lock_guard<std::mutex> lock(g_overlap_mu);
         for (bn_mppi *o : g_handles[h->cfg.device_id]) {
@@ -1431,19 +1566,27 @@ static bool hp_prelaunch(bn_mppi *h)
     }
     h->hp_seq = tag;
     p.req_tag = tag;
-    p.req_polls = h->hp_polls;                         // ~50 ms at ~2 us a look
-    p.req_host = h->d_req + (size_t)slot * 8;
+    p.req_direct = h->req_bar ? 1 : 0;
+    // the launch's patience, in looks: ~2 us each over PCIe, ~0.7 us in device memory -- at least 50 ms either way; the host stays
+    // below 20 ms (hp_post looks at the clock), so a "go" never meets a "gave up"
+    p.req_polls = (h->req_bar && h->hp_polls == 25000) ? 100000 : h->hp_polls;
+    p.req_host = (h->req_bar ? h->req_bar : h->d_req) + (size_t)slot * 8;
     p.req_dev = h->d_req_dev + (size_t)slot * 8;
     p.spec_status = h->d_req + (size_t)kSlots * 8;
     p.state = h->d_state;                              // (not read: the state comes with the request)
     const int q = h->hp_next_q;
-    const hipError_t e = p.ref_order ? bn::launch_rollout_lat_host_ref(p, h->hp_stream[q]) : bn::launch_rollout_lat_host(p, h->hp_stream[q]);
+#ifdef BN_TIMING
+    g_hpc[2].ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - bn_t_pre).count(); g_hpc[2].n += 1;
+#endif
+    hipError_t e;
+    { BN_HP_TICK(3); e = p.ref_order ? bn::launch_rollout_lat_host_ref(p, h->hp_stream[q]) : bn::launch_rollout_lat_host(p, h->hp_stream[q]); }
     if (e != hipSuccess) { (void)hipGetLastError(); h->hp_enabled = false; return false; }
-    if (hipEventRecord(h->hp_ev[q], h->hp_stream[q]) != hipSuccess) (void)hipGetLastError();
+    { BN_HP_TICK(4); if (hipEventRecord(h->hp_ev[q], h->hp_stream[q]) != hipSuccess) (void)hipGetLastError(); }
     h->pub[cur3] += (unsigned long long)p.nblk;
     h->tails += 1;
     h->solves += 1;
     h->hp_armed = true; h->hp_tag = tag; h->hp_slot = slot; h->hp_q = q; h->hp_xidx = xi;
+    h->hp_armed_at = std::chrono::steady_clock::now();
     h->hp_next_q = 1 - q;
     return true;
 }
@@ -1457,7 +1600,7 @@ static int hp_post(bn_mppi *h, const float st[3], float *out_device)
     // have completed; fresh output blocks per step (what the drop-in class hands out) need nothing.  (Asking the stream -- hipStreamQuery
     // -- is no way out: the event that orders the previous solve's launch in front of the caller's consumers keeps it "busy" for tens of
     // microseconds after that launch has ended, and every step would wait for it: 17 -> 39 us, measured.)
-    hp_write_request(h, h->hp_slot, h->hp_tag, st, out_device, 1u);
+    { BN_HP_TICK(0); hp_write_request(h, h->hp_slot, h->hp_tag, st, out_device, 1u); }
     h->hp_armed = false;
     h->hp_posted_tag = h->hp_tag;
     std::memcpy(h->hp_posted_state, st, 12);
@@ -1470,7 +1613,7 @@ static int hp_post(bn_mppi *h, const float st[3], float *out_device)
     h->self_used = true;
     h->hp_gran_valid = true;
     // whatever the caller enqueues on the handle's stream from here on is ordered behind this solve's launch (its outputs)
-    BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[h->hp_q], 0));
+    { BN_HP_TICK(1); BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[h->hp_q], 0)); }
     return BN_OK;
 }
 
@@ -1483,7 +1626,10 @@ static int forward_impl(bn_mppi_t *h, const float *states_device, const float *s
     if (!states_device && !state_host) return fail(BN_ERR_INVALID, "states is null");
     if ((noise == BN_NOISE_PHILOX) != (eps_device == nullptr)) return fail(BN_ERR_INVALID, "eps must be NULL exactly when noise == BN_NOISE_PHILOX");
     const bool paced = h->hp_enabled && state_host && noise == BN_NOISE_PHILOX && !h->self_off;
-    if (paced && h->hp_armed && !h->hp_skip_check && hp_gave_up(h, h->hp_tag)) hp_cancel(h);      // (the host took longer than the launch waits: start over below)
+    // (the host took longer than the launch waits -- or, with the request words polled by every workgroup of the launch, may be about
+    // to: a "go" must never meet a "gave up" -- : start over below)
+    if (paced && h->hp_armed && !h->hp_skip_check &&
+        (hp_gave_up(h, h->hp_tag) || std::chrono::steady_clock::now() - h->hp_armed_at > std::chrono::milliseconds(20))) hp_cancel(h);
     if (paced && h->hp_armed) {                        // the loop's steady state: the launch is there and waits for exactly this
         BN_BIND(h);
         if (int rc = self_check(h)) return rc;
@@ -2480,7 +2626,7 @@ int bn_mppi_device_buffer(bn_mppi_t *h, bn_buffer_id id, void **device_ptr, size
 }
 
 uint64_t bn_mppi_solve_count(const bn_mppi_t *h) { return h ? h->solves - (h->hp_armed ? 1 : 0) : 0; }
-int32_t bn_mppi_host_paced(const bn_mppi_t *h) { return h ? (h->hp_enabled ? 1 : 0) : -1; }
+int32_t bn_mppi_host_paced(const bn_mppi_t *h) { return h ? (h->hp_enabled ? (h->req_bar ? 2 : 1) : 0) : -1; }
 int32_t bn_mppi_states_buffer_index(const bn_mppi_t *h) { return h ? h->x_idx : -1; }
 
 int32_t bn_mppi_arithmetic(const bn_mppi_t *h) { return h ? h->p.ref_order : -1; }

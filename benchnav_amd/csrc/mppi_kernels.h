@@ -137,6 +137,7 @@ struct SolveParams {
     const unsigned long long *req_host;     // pinned host memory: kReqGranules {value, tag = solve + 1} granules -- x, y, theta, out pointer lo / hi, command
     unsigned long long *req_dev;            // device memory: the same granules as the launch's tail workgroup republishes them (the launch's one decision)
     unsigned long long *spec_status;        // pinned host memory: {2, tag} when the tail workgroup gave up waiting for the host
+    int req_direct;                         // req_host is DEVICE memory the host writes through the PCIe BAR: the rollout workgroups poll it themselves (no republishing hop)
     uint32_t req_tag;                       // this launch's request tag (unique per prelaunch: a cancelled launch and its successor never share one)
     int req_polls;                          // how often the tail workgroup looks for the request before it gives up (~2 us a look)
     int state_inline;    // the (one) instance's state travels in the kernel arguments (sv): a host loop that hands over a fresh state
@@ -194,6 +195,7 @@ hipError_t launch_env_collision(const SolveParams &p, const float *states, int N
 // set the flag (bounded) and records in [1] whether its first workgroup saw it: only if the two streams dispatch concurrently.
 hipError_t launch_queue_probe(int *flag_and_seen, hipStream_t waiter, hipStream_t setter, int n_cus);
 // every float d in [0, d_max]: does quotient_general's fast form give floor(d / res) (and the same bits for d >= 1e-30)?  *bad = count of failures
+hipError_t launch_echo64(const unsigned long long *src, unsigned long long *dst, hipStream_t s);   // one thread: *dst = *src (system scope both ways)
 hipError_t launch_stamp(int *word, int value, hipStream_t s);      // one thread: *word = value (system scope) -- a marker in a queue, for the host
 hipError_t launch_quotient_check(float res, float inv_res, float d_max, unsigned long long *bad, hipStream_t s);
 hipError_t launch_math_eval(int fn, const float *in, float *out, size_t n, hipStream_t s);   // 0 sqrt, 1 sin, 2 cos, 3 wrap, 4 wrap_near

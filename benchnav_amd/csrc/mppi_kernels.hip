@@ -630,6 +630,17 @@ __global__ void stamp_kernel(int *word, int value)
     __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__global__ void echo64_kernel(const unsigned long long *src, unsigned long long *dst)
+{
+    __hip_atomic_store(dst, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_echo64(const unsigned long long *src, unsigned long long *dst, hipStream_t s)
+{
+    echo64_kernel<<<1, 1, 0, s>>>(src, dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_stamp(int *word, int value, hipStream_t s)
 {
     stamp_kernel<<<1, 1, 0, s>>>(word, value);

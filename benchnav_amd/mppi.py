@@ -211,7 +211,7 @@ class MPPI(nn.Module):
         K, T = num_samples, horizon
         Kp = int(lib.bn_mppi_row_pitch(self._handle))        # rows are pitched to 64*ceil(K/64) floats
         self._buf_X = None if lean else self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, Kp))[:, :, :K]
-        self._host_loop = int(lib.bn_mppi_host_paced(self._handle)) == 1
+        self._host_loop = int(lib.bn_mppi_host_paced(self._handle)) >= 1
         # host-paced solves alternate between two trajectory / control buffers (two launches in flight): bn_mppi_states_buffer_index
         self.__dict__["_buf_X_alt"] = self._wrap(_capi.BN_BUF_STATES_ALT, (T + 1, 3, Kp))[:, :, :K] if (self._host_loop and not lean) else None
         self._buf_w = self._wrap(_capi.BN_BUF_WEIGHTS, (K,))
@@ -346,19 +346,26 @@ class MPPI(nn.Module):
 
     _OUT_POOL = 32      # fresh output tensors are carved from blocks of this many (one torch.empty per 32 forwards)
 
-    def _new_out_block(self):
-        """Fresh (U*, X*) tensors for the next _OUT_POOL forwards: ONE allocation, views made in bulk (the reference returns new tensors
-        from every forward(); a torch.empty and two as_strided per call were 5 of the drop-in step's microseconds)."""
+    def _alloc_out_block(self):
+        """(block, U views, X views, base pointer, event) for _OUT_POOL forwards: ONE allocation, views made in bulk (the reference returns new
+        tensors from every forward(); a torch.empty and two as_strided per call were 5 of the drop-in step's microseconds).  host_loop:
+        the launches that will write the block run on a stream of the library's own, and the memory torch's allocator hands out may have
+        been freed with reads still queued on torch's stream (ordered for work on THAT stream only): an event recorded now covers them."""
         n, T, no = self._OUT_POOL, self._horizon, self._n_out
-        if self._host_loop:
-            # host-loop launches run on a stream of the library's own: the block torch's allocator hands out next may have been freed
-            # with reads still queued on torch's stream -- ordered for work on THAT stream, not for ours.  Once per _OUT_POOL forwards.
-            torch.cuda.current_stream(self._device).synchronize()
         blk = torch.empty(n, no, device=self._device, dtype=self._dtype)
+        ev = None
+        if self._host_loop:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self._device))
+        return blk[:, :2 * T].view(n, T, 2), blk[:, 2 * T:].view(n, 1, T + 1, 3), blk.data_ptr(), ev
+
+    def _new_out_block(self):
+        """Switch to the next output block -- allocated half a block ago (host_loop: its event has long fired by now, no wait)."""
         d = self.__dict__
-        d["_out_U"] = blk[:, :2 * T].view(n, T, 2)
-        d["_out_X"] = blk[:, 2 * T:].view(n, 1, T + 1, 3)
-        d["_out_ptr"] = blk.data_ptr()
+        nxt = d.pop("_out_next", None) or self._alloc_out_block()
+        if nxt[3] is not None and not nxt[3].query():
+            nxt[3].synchronize()
+        d["_out_U"], d["_out_X"], d["_out_ptr"] = nxt[0], nxt[1], nxt[2]
         d["_out_i"] = 0
 
     def forward(self, state: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -402,6 +409,8 @@ class MPPI(nn.Module):
                 i = 0
             d["_out_i"] = i + 1
             optr = d["_out_ptr"] + i * self._n_out * 4
+            if i == self._OUT_POOL // 2:
+                d["_out_next"] = self._alloc_out_block()
         if _raw_stream(self._dev_index) == self._stream_id:
             rc = fwd(self._h, state.data_ptr(), eptr, kind, optr)   # solve + tail: U*, X*, weights of THIS solve, stream-ordered
         else:

@@ -162,7 +162,7 @@ class NativeMPPI:
 
     def host_paced(self) -> bool:
         """BN_FLAG_HOST_PACED was given and the handle qualifies: forward_state_async enqueues the next solve's launch one step ahead."""
-        return int(self._lib.bn_mppi_host_paced(self._h)) == 1
+        return int(self._lib.bn_mppi_host_paced(self._h)) >= 1
 
     def states_buffer_index(self) -> int:
         return int(self._lib.bn_mppi_states_buffer_index(self._h))

@@ -224,7 +224,8 @@ int bn_mppi_forward_state_async(bn_mppi_t *h, const float *states_host, const fl
  *     those 50 ms: end the loop with any other call of the handle (bn_mppi_flush is the cheapest) first.  This is why the mode is
  *     opt-in;
  *   - a state more than two cells from the previous one (a reset) is handled inside the waiting launch (it stages its window again). */
-int32_t bn_mppi_host_paced(const bn_mppi_t *h);      /* 1: BN_FLAG_HOST_PACED was given and the handle qualifies */
+int32_t bn_mppi_host_paced(const bn_mppi_t *h);      /* 0: no; 1: BN_FLAG_HOST_PACED was given and the handle qualifies; 2: ... and the request words live in
+                                                         device memory the host writes through the PCIe BAR (no PCIe read on the launch's side) */
 /* Which of the two trajectory / control buffers holds the LATEST solve (0: BN_BUF_STATES / BN_BUF_CONTROLS, 1: the *_ALT ones): host-paced
  * solves alternate between them (two launches are in flight and must not write the same addresses); every other path writes buffer 0. */
 int32_t bn_mppi_states_buffer_index(const bn_mppi_t *h);

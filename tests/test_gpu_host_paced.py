@@ -38,6 +38,7 @@ def _run(pl, states, T, events=None, sleep_at=(), sleep_s=0.0):
         if i in sleep_at:
             time.sleep(sleep_s)
         o = torch.full((n_out,), float("nan"), device="cuda")
+        torch.cuda.current_stream().synchronize()            # the mode's contract: nothing queued on the planner's stream still uses the block handed over
         pl.forward_state_async(st, None, 0, o.data_ptr())
         acts.append(pl.first_action().copy())
         outs.append(o)

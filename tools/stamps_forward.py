@@ -63,4 +63,6 @@ print(f"host: forward call {host[0]:.1f} us | first_action wait {host[1]:.1f} us
 ref0 = "the rollout wg saw go" if paced else "the rollout wg's start"
 print("rollout wg(0,0), us after %s: start %.2f | ready, polls for the request %.2f | prologue end %.2f | chunk0 %.2f | chain end %.2f | after barrier %.2f | column sums out %.2f" % ((ref0,) + tuple(rel[:7])))
 print("self tail, us after %s: enter %.2f | window staged %.2f | rows seen %.2f | merged + mailbox %.2f | X* rolled %.2f | all waves %.2f | end %.2f | (paced) request taken from the host %.2f" % ((ref0,) + tuple(rel[7:])))
+if paced and hasattr(lib, "bn_mppi_debug_hp_clock"):
+    lib.bn_mppi_debug_hp_clock()
 pl.close()
