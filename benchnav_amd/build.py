@@ -12,10 +12,13 @@ LIB_PATH = os.path.join(LIB_DIR, "libbenchnav_mppi.so")
 # one translation unit per kernel family: they compile in parallel (the role kernel alone is 72 template instances)
 SOURCES = ["rollout_role_philox.hip", "rollout_role_kt2.hip", "rollout_role_t2k.hip", "rollout_role_ref_philox.hip", "rollout_role_ref_kt2.hip", "rollout_role_ref_t2k.hip", "rollout_wave.hip", "rollout_wave_ref.hip", "rollout_sampled.hip",
            "rollout_lat_host.hip", "rollout_lat_host_ref.hip",
+           "rollout_lat_self_philox.hip", "rollout_lat_self_kt2.hip", "rollout_lat_self_t2k.hip",
+           "rollout_lat_self_ref_philox.hip", "rollout_lat_self_ref_kt2.hip", "rollout_lat_self_ref_t2k.hip",
            "mppi_kernels.hip", "mppi_capi.cpp", "risk_kernels.hip"]
 # per-source flags.  rollout_wave_ref.hip: see the note at its top (a register-allocation fault behind the SLP vectoriser)
 EXTRA_FLAGS = {f: ["-fno-slp-vectorize"] for f in ("rollout_wave_ref.hip", "rollout_role_ref_philox.hip", "rollout_role_ref_kt2.hip", "rollout_role_ref_t2k.hip",
-                                                      "rollout_lat_host_ref.hip")}
+                                                      "rollout_lat_host_ref.hip", "rollout_lat_self_ref_philox.hip", "rollout_lat_self_ref_kt2.hip",
+                                                      "rollout_lat_self_ref_t2k.hip")}
 # every header / include file under csrc/ (globbed: a new .inc cannot be forgotten here) + the public header
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "benchnav_mppi.h")]
 

@@ -1404,7 +1404,8 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
         // more workgroups than the role kernel keeps resident at once (4 per CU x 256 CUs): the aux workgroups run in freed slots
         p.aux_prio = (!p.wave_kernel && (size_t)p.B * (p.nblk + 1) > h->resident_wgs) ? 1 : 0;
         if (!p.wave_kernel && !p.store_u) p.U = nullptr;          // the buffer exists for the throughput kernel only
-        BN_HIP(bn::launch_rollout(p, mode, st));
+        if (p.self_tail) BN_HIP(bn::launch_rollout_lat_self(p, mode, st));    // (a kernel of its own: rollout_lat.inc, mode 1)
+        else BN_HIP(bn::launch_rollout(p, mode, st));
         if (prof_grouped) h->prof_in_group = (h->prof_in_group + 1) % kProfGroup;
         h->solves += 1;
         h->x_idx = 0;                                  // (batches end on the exposed buffers, bn_mppi_solve_n_async)
@@ -2020,10 +2021,11 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         BN_HIP(hipEventRecord(h->ev_fork, h->stream));              // (nothing is: no event packet in front of the first launches)
         for (int q = 0; q + 1 < S; ++q) BN_HIP(hipStreamWaitEvent(h->xstream[q], h->ev_fork, 0));
     }
-    // The last launch of a long batch can carry its own tail as a second aux workgroup (SolveParams::self_tail) instead of a tail
-    // kernel behind it.  Measured (tools/region_overhead.py, K = 20): 0.7 us better with round 2's kernel, 5 us WORSE since the
-    // barrier-free prologue (225.2 vs 230.2 us) -- off unless BN_SELF_TAIL is set; the code stays for the next look at the region's ends.
-    const bool exp_self_tail = exp_env("BN_SELF_TAIL") != nullptr;      // (read per batch: tools/region_ab.py toggles it inside one process)
+    // The last launch of a long batch carries its own tail as a second aux workgroup (SolveParams::self_tail; the one-launch kernel,
+    // rollout_lat.inc mode 1) instead of a tail kernel behind it: since round 6 that workgroup stages its window while the rollouts run
+    // and polls the granules of their rows -- 3 us off a 20-solve region (tools/region_ab.py: 215.2 -> 212.2 us; the counter-waiting
+    // tail of rounds 2-5 had measured 5 us WORSE than the kernel behind).  BN_NO_SELF_TAIL (experiment builds) turns it off.
+    const bool exp_self_tail = exp_env("BN_NO_SELF_TAIL") == nullptr;      // (read per batch: tools/region_ab.py toggles it inside one process)
     static const bool exp_align = exp_env("BN_NO_ALIGN") == nullptr;
     if (!exp_align) idle = false;                                   // (only the stream assignment below looks at it from here on)
     // Launches big enough to crowd each other out start on the handle's OWN stream, whatever that costs at the batch's end.  Aligning

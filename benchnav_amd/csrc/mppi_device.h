@@ -954,7 +954,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         for (int j = tid; j < 2 * T; j += NT) {
             const float u = ld<AGENT>(p.ustar_prev + (size_t)b * 2 * T + j);
             us[j] = u;
-            if (!p.ustar_written) st<AGENT>(p.ustar + (size_t)b * 2 * T + j, u);
+            if (!(BIG && p.ustar_written)) st<AGENT>(p.ustar + (size_t)b * 2 * T + j, u);      // (BIG: the stand-alone tail, the only one that follows a merge kernel)
             if (p.out_copy) st<AGENT>(p.out_copy + (size_t)b * 2 * T + j, u);
         }
         m = ld<AGENT>(p.stats_prev + b * 2 + 0);
@@ -1341,6 +1341,12 @@ static int grid_for(size_t n) { return (int)((n + 255) / 256 > 2048 ? 2048 : (n 
 hipError_t launch_rollout_role_philox(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_kt2(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_t2k(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_lat_self_philox(const SolveParams &p, hipStream_t s);    // rollout_lat_self_*.hip
+hipError_t launch_rollout_lat_self_kt2(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_lat_self_t2k(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_lat_self_ref_philox(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_lat_self_ref_kt2(const SolveParams &p, hipStream_t s);
+hipError_t launch_rollout_lat_self_ref_t2k(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_ref_philox(const SolveParams &p, hipStream_t s);   // rollout_role_ref_*.hip: BN_FLAG_REFERENCE_ORDER
 hipError_t launch_rollout_role_ref_kt2(const SolveParams &p, hipStream_t s);
 hipError_t launch_rollout_role_ref_t2k(const SolveParams &p, hipStream_t s);

@@ -102,8 +102,6 @@ struct SolveParams {
     float *ustar_cur, *stats_cur;      // (B, T, 2), (B, 2): merge outputs of this solve (double-buffered by solve parity)
     const float *ustar_prev, *stats_prev;   // merge outputs of the solve whose tail this launch / the stand-alone tail writes
     int tail_merged;                   // the tail reads (ustar_prev, stats_prev) instead of merging `part`
-    int ustar_written;                 // ... and U* itself is in `ustar` already (the K-sharded solve's merge kernel wrote it on the handle's stream:
-                                       // a tail on the side stream must not write it again behind the NEXT solve's merge)
     uint64_t tail_solve;               // index of the solve whose tail is written (its X* draws)
     // ---- overlapped launches (solve_n_overlapped in mppi_capi.cpp): consecutive solves alternate between two streams, so a launch
     // may start while its predecessor still runs; what stream order used to guarantee is carried by monotonic device counters ----
@@ -130,6 +128,12 @@ struct SolveParams {
                                 // done -- before the X* rollout and the weights -- for a host that consumes every solve (bn_mppi_first_action)
     float *out_copy;     // optional caller-owned copy of the packed (B,T,2) U* | (B,T+1,3) X* block, written by the same tail
                          // (bn_mppi_forward_async: the drop-in class's fresh output tensors without a second launch)
+    float *stats;        // (B, 2): max z, sum exp
+    int trace_by_parity;          // timing builds: per-workgroup trace rows of odd solves behind those of even solves (two launches in flight)
+    unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0
+    // ---- round 6, appended: the fields above keep the offsets the round-5 kernels were tuned with ----
+    int ustar_written;                 // ... and U* itself is in `ustar` already (the K-sharded solve's merge kernel wrote it on the handle's stream:
+                                       // a tail on the side stream must not write it again behind the NEXT solve's merge)
     float *out_copy_self;   // ... the same for the tail of THIS launch's solve (self_tail): the aux workgroup of the previous solve's tail
                             // in the same launch must not write the caller's block
     // ---- host-paced launches (rollout_lat.inc HOSTP; bn_mppi_forward_state_async in a loop) ----
@@ -142,9 +146,6 @@ struct SolveParams {
     int req_polls;                          // how often the tail workgroup looks for the request before it gives up (~2 us a look)
     int state_inline;    // the (one) instance's state travels in the kernel arguments (sv): a host loop that hands over a fresh state
     float sv[3];         // every control step (bn_mppi_forward_state_async) pays neither an upload nor the prologue's fetch of it
-    float *stats;        // (B, 2): max z, sum exp
-    int trace_by_parity;          // timing builds: per-workgroup trace rows of odd solves behind those of even solves (two launches in flight)
-    unsigned long long *stamps;   // tools/ablate.py timing builds only (-DBN_TIMING): s_memtime stamps of block 0
 };
 
 constexpr int kFlagStride = 32;            // spacing of the overlap counters, in counters of 8 bytes: 256 bytes, one memory channel each
@@ -170,6 +171,7 @@ size_t lat_lds_bytes(const SolveParams &p);       // 0 when the latency variant 
 int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer for the headline rollout kernel (diagnostics)
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
+hipError_t launch_rollout_lat_self(const SolveParams &p, EpsMode mode, hipStream_t s);   // the one-launch latency kernel (rollout_lat.inc mode 1: the solve's own tail in the launch)
 hipError_t launch_rollout_lat_host(const SolveParams &p, hipStream_t s);       // the host-paced latency kernel (Philox noise), rollout_lat_host.hip
 hipError_t launch_rollout_lat_host_ref(const SolveParams &p, hipStream_t s);   // ... in the reference's operation order
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);

@@ -491,6 +491,21 @@ hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s)
     }
 }
 
+hipError_t launch_rollout_lat_self(const SolveParams &p, EpsMode mode, hipStream_t s)
+{
+    if (p.ref_order)
+        switch (mode) {
+        case kEpsPhilox: return launch_rollout_lat_self_ref_philox(p, s);
+        case kEpsKT2: return launch_rollout_lat_self_ref_kt2(p, s);
+        default: return launch_rollout_lat_self_ref_t2k(p, s);
+        }
+    switch (mode) {
+    case kEpsPhilox: return launch_rollout_lat_self_philox(p, s);
+    case kEpsKT2: return launch_rollout_lat_self_kt2(p, s);
+    default: return launch_rollout_lat_self_t2k(p, s);
+    }
+}
+
 hipError_t launch_shard_merge(const SolveParams &p, float *group_rows, int *ticket, hipStream_t s)
 {
     if (p.nblk > 64 * kGroupRows) return hipErrorInvalidValue;       // (K > 65536: not sharded through the library's exchange)

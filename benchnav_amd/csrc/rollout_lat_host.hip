@@ -2,7 +2,7 @@
 // device for the state the host posts (bn_mppi_forward_state_async in a loop).  Philox noise only; a translation unit of its own.
 #define BN_ROLE_EPS kEpsPhilox
 #define BN_ROLE_REF false
-#define BN_LAT_HOSTP true
+#define BN_LAT_MODE 2
 #include "mppi_device.h"
 #include "rollout_lat.inc"
 

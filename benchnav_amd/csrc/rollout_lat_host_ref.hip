@@ -2,7 +2,7 @@
 // rollout_lat_host.hip.  Compiled without the SLP vectoriser like the other reference-order units (benchnav_amd/build.py).
 #define BN_ROLE_EPS kEpsPhilox
 #define BN_ROLE_REF true
-#define BN_LAT_HOSTP true
+#define BN_LAT_MODE 2
 #include "mppi_device.h"
 #include "rollout_lat.inc"
 
