@@ -903,7 +903,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
     float sx, sy, sth;
     BN_SSTAMP(0);
     if constexpr (SELF) {                              // the state this launch's rollouts start from: the caller's, known from the start
-        if (p.state_inline) { sx = p.sv[0]; sy = p.sv[1]; sth = p.sv[2]; }
+        if (p.state_inline) { sx = p.sv0; sy = p.sv1; sth = p.sv2; }
         else { sx = p.state[b * 3 + 0]; sy = p.state[b * 3 + 1]; sth = p.state[b * 3 + 2]; }
     } else {
         sx = ld<AGENT>(state_all + b * 3 + 0); sy = ld<AGENT>(state_all + b * 3 + 1); sth = ld<AGENT>(state_all + b * 3 + 2);

@@ -145,7 +145,9 @@ struct SolveParams {
     uint32_t req_tag;                       // this launch's request tag (unique per prelaunch: a cancelled launch and its successor never share one)
     int req_polls;                          // how often the tail workgroup looks for the request before it gives up (~2 us a look)
     int state_inline;    // the (one) instance's state travels in the kernel arguments (sv): a host loop that hands over a fresh state
-    float sv[3];         // every control step (bn_mppi_forward_state_async) pays neither an upload nor the prologue's fetch of it
+    float sv0, sv1, sv2; // (three scalars, not an array: the tail workgroup works on a modified copy of this struct, and an array member
+                         // of a copied struct lands in a scratch segment -- tests/test_build_artifacts.py)
+                         // every control step (bn_mppi_forward_state_async) pays neither an upload nor the prologue's fetch of it
 };
 
 constexpr int kFlagStride = 32;            // spacing of the overlap counters, in counters of 8 bytes: 256 bytes, one memory channel each
