@@ -84,6 +84,8 @@ SYMBOLS = {
     "bn_mppi_dwa_buffers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "bn_mppi_sync": (C.c_int, [_H]),
     "bn_mppi_recovery_count": (C.c_uint64, [_H]),
+    "bn_mppi_overlap_mode": (C.c_int32, [_H]),
+    "bn_mppi_debug_cadence": (C.c_int, [_H, C.c_int32, C.c_double]),
     "bn_mppi_first_action": (C.c_int, [_H, C.c_int32, _FP]),
     "bn_mppi_debug_expire_wait": (C.c_int, [_H]),
     "bn_mppi_flush": (C.c_int, [_H]),

@@ -209,6 +209,15 @@ struct bn_mppi {
     bool arm_snap = false;                      // the next launch keeps its mean in d_mean_snap
     bool replaying = false, last_batch_overlapped = false;
     uint64_t journal_solves0 = 0, recoveries = 0;
+    // Self-protecting overlap (round 6).  Overlapped launches assume the device to themselves: with a co-tenant process on the GPU the
+    // workgroups that wait for their predecessor hold slots the predecessor's stragglers need, and the chain runs at HALF the
+    // one-stream rate (46 k against 80 k solves/s).  The handle watches its own cadence -- the first-action mailbox
+    // counts finished solves, the host clock does the rest: no event, no kernel change -- over windows of 64 launches that found the
+    // device backlogged at both ends, looks at the other mode once, and runs whichever is faster; it looks again when its cadence
+    // degrades by half, and every 256 windows while it runs on one stream (has the co-tenant left?).
+    struct OvTune { double best[2] = {0, 0}, last[2] = {0, 0}; int chosen = 0, explore = 0; uint64_t windows[2] = {0, 0}, since_explore = 0, switches = 0; } tune;
+    struct OvSample { bool valid = false; std::chrono::steady_clock::time_point t{}; uint32_t prog = 0, enq = 0; } ov_sample;
+    int run_mode = 0;                // the mode of the batch being enqueued (0 overlapped, 1 one stream)
     // One launch per SYNCHRONOUS solve (round 6; bn_mppi_forward_async, bn_mppi_forward_state_async, bn_mppi_solve on the latency kernel):
     // the solve's own tail rides in its launch as a second aux workgroup (SolveParams::self_tail) -- no stand-alone finish kernel.
     float *self_out_copy = nullptr;  // the caller's U* | X* block of the forward() being enqueued (consumed by solve_impl)
@@ -635,6 +644,44 @@ int settle_point(bn_mppi *h)
     if (!h->overlap_used || h->replaying) return BN_OK;
     if (int rc = flush_tail(h)) return rc;
     return sync_checked(h);
+}
+
+void tune_record(bn_mppi *h, int mode, double us)
+{
+    bn_mppi::OvTune &t = h->tune;
+    t.last[mode] = us;
+    if (t.best[mode] == 0 || us < t.best[mode]) t.best[mode] = us;
+    t.windows[mode] += 1;
+    if (mode == t.chosen) {
+        if (t.chosen == 0) {
+            if (t.best[1] == 0) { if (t.windows[0] >= 2) t.explore = 1; }                          // never seen the other mode: look once
+            else if (us > 1.5 * t.best[0]) {
+                if (us > 1.15 * t.best[1]) { t.chosen = 1; t.switches += 1; t.since_explore = 0; }   // somebody else is on the device: the waiting workgroups hurt
+                else t.explore = 1;
+            }
+        } else if (++t.since_explore >= 256) { t.explore = 1; t.since_explore = 0; }              // has the co-tenant left?
+    } else {                                           // a look at the other mode
+        if (t.last[t.chosen] > 0 && us < 0.9 * t.last[t.chosen]) { t.chosen = mode; t.switches += 1; t.since_explore = 0; }
+        t.explore = 0;
+    }
+}
+
+// Every 64 launches of a batch: how many solves has the device finished (the tails post the first action with the solve's index), and when.
+// Two samples that both found the device behind the host give a cadence; anything else says nothing.
+void tune_sample(bn_mppi *h)
+{
+    if (!h->h_mail || h->in_episode || h->replaying) return;
+    bn_mppi::OvSample now;
+    now.valid = true;
+    now.t = std::chrono::steady_clock::now();
+    now.prog = (uint32_t)(__atomic_load_n(h->h_mail, __ATOMIC_ACQUIRE) >> 32);
+    now.enq = (uint32_t)h->solves;
+    const bn_mppi::OvSample &pr = h->ov_sample;
+    if (pr.valid && (int32_t)(pr.enq - now.prog) > 0 && (int32_t)(now.prog - pr.prog) >= 16 && (int32_t)(pr.enq - pr.prog) >= 2) {
+        const double us = std::chrono::duration<double, std::micro>(now.t - pr.t).count() / (double)(now.prog - pr.prog);
+        tune_record(h, h->run_mode, us);
+    }
+    h->ov_sample = now;
 }
 
 }  // namespace
@@ -1950,8 +1997,13 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // device-scope loads after its wait (64 instances: 29.6 -> 24.8 us per control step).
     const bool overlap = (h->lat_kernel || h->role_overlap || h->ticket_overlap) && h->n_streams > 1 && (h->d_Xalt[0] || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE &&
                          noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending && !h->overlap_off;
-    bool mine = overlap;
-    if (overlap) {                                      // see g_overlap_owner
+    // which mode this batch runs in: the handle's choice, or -- once -- the other one, for a look (tune_record)
+    int mode = overlap ? h->tune.chosen : 1;
+    if (overlap && h->tune.explore && n >= 128 && !h->in_episode) mode = 1 - h->tune.chosen;
+    if (mode != h->run_mode) h->ov_sample.valid = false;
+    h->run_mode = mode;
+    bool mine = overlap && mode == 0;
+    if (mine) {                                         // see g_overlap_owner
         BN_BIND(h);
         std::lock_guard<std::mutex> lock(g_overlap_mu);
         bn_mppi *&owner = g_overlap_owner[h->cfg.device_id];
@@ -1992,6 +2044,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
         for (int32_t i = 0; i < n; ++i) {
             const float *e = eps ? eps + (size_t)(i % eps_ring) * (size_t)eps_stride : nullptr;
             if (int rc = solve_impl(h, states, states_where, e, noise, false)) return rc;
+            if (overlap && (i & 63) == 63) tune_sample(h);
         }
         if (!h->in_episode) journal_push(h, rec, replayable);   // behind an overlapped batch not yet checked: lost with it, re-run with it
         return BN_OK;
@@ -2092,6 +2145,7 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
             }
         }
         rc = solve_impl(h, states, states_where, e, noise, false, true, qs, q, own_tail);
+        if ((i & 63) == 63) tune_sample(h);
     }
     // A long batch ends with its own tail, enqueued right behind the last solve and BEFORE the join: a tail kernel that comes later
     // (flush, sync, a getter) would sit behind the join's barrier packet, ~10 us of queue processing after the last rollout kernel.
@@ -2344,6 +2398,22 @@ int bn_mppi_sync(bn_mppi_t *h)
 }
 
 uint64_t bn_mppi_recovery_count(const bn_mppi_t *h) { return h ? h->recoveries : 0; }
+
+int32_t bn_mppi_overlap_mode(const bn_mppi_t *h)
+{
+    if (!h) return -1;
+    const bool capable = (h->lat_kernel || h->role_overlap || h->ticket_overlap) && h->n_streams > 1 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP));
+    if (!capable) return 3;
+    if (h->overlap_off) return 2;
+    return h->tune.chosen ? 1 : 0;
+}
+
+int bn_mppi_debug_cadence(bn_mppi_t *h, int32_t mode, double us_per_launch)
+{
+    if (!h || mode < 0 || mode > 1 || !(us_per_launch > 0)) return fail(BN_ERR_INVALID, "bad argument");
+    tune_record(h, mode, us_per_launch);
+    return h->tune.explore ? 1 : 0;
+}
 
 int bn_mppi_first_action(bn_mppi_t *h, int32_t instance, float action_host[2])
 {

@@ -282,6 +282,10 @@ class NativeMPPI:
         """How many times batches were re-run after an expired device-side wait of an overlapped launch (0 normally)."""
         return int(self._lib.bn_mppi_recovery_count(self._h))
 
+    def overlap_mode(self) -> int:
+        """0 overlapped, 1 one stream by the handle's own choice (a co-tenant on the device), 2 one stream after an expired wait, 3 never overlaps."""
+        return int(self._lib.bn_mppi_overlap_mode(self._h))
+
     def flush(self):
         """Enqueue the pending tail (U*, X*, weights of the latest solve) without waiting."""
         _capi.check(self._lib.bn_mppi_flush(self._h))

@@ -378,6 +378,18 @@ int bn_mppi_sync(bn_mppi_t *h);
 int bn_mppi_first_action(bn_mppi_t *h, int32_t instance, float action_host[2]);
 /* How many times this handle re-ran batches after an expired device-side wait (0 in normal operation). */
 uint64_t bn_mppi_recovery_count(const bn_mppi_t *h);
+/* Which way bn_mppi_solve_n_async runs its batches (ABI 4).  Overlapped launches assume the DEVICE TO THEMSELVES: the workgroups of
+ * launch i+1 wait, resident, for launch i's partials, and with another process's kernels on the GPU those waiting workgroups hold the
+ * slots launch i's stragglers need -- the chain then runs at half the one-stream rate (and, in the extreme, a bounded wait expires:
+ * see above).  The handle protects itself: it measures its own cadence over windows of 64 launches (the first-action mailbox counts
+ * finished solves; no event, no kernel change), looks at the other mode once, keeps the faster one, looks again when its cadence
+ * degrades by half and -- while on one stream -- every 256 windows.
+ *   0  overlapped (two streams)      1  one stream, by the handle's own choice (somebody else is on the device)
+ *   2  one stream for good: a device-side wait expired once (bn_mppi_recovery_count)      3  the handle never overlaps (flags, kernel family) */
+int32_t bn_mppi_overlap_mode(const bn_mppi_t *h);
+/* Test hook: feed the tuner a cadence (microseconds per launch) measured in `mode` (0 overlapped, 1 one stream); returns 1 when the
+ * next long batch will look at the other mode. */
+int bn_mppi_debug_cadence(bn_mppi_t *h, int32_t mode, double us_per_launch);
 /* Test hook: behave as if a bounded device-side wait had expired in the batches enqueued since the last synchronisation point
  * (what happens when another process keeps a launch's predecessor from becoming resident for ~2 s): sets the error word and
  * overwrites what those batches wrote (mean, U* | X*, weights, costs, trajectories) with NaN patterns.  The next synchronising

@@ -411,3 +411,55 @@ def test_sampled_slip_launches_overlap_bit_identically():
             assert pl.solve_count() == 9
     for a_, b_ in zip(res[True], res[False]):
         assert np.array_equal(a_, b_)
+
+
+def test_overlap_mode_getter_and_the_tuners_policy():
+    """bn_mppi_overlap_mode (ABI 4) and the policy behind it, fed through the test hook: a handle looks at the one-stream mode once, stays
+    overlapped while that is faster, moves to one stream when its own cadence degrades by half AND one stream beats it (a co-tenant on
+    the device), looks back every 256 windows, and returns when the device is its own again.  An expired wait ends overlapping for good."""
+    import torch
+    from benchnav_amd import NativeMPPI, _capi, synth
+    inst = synth.make_instance(128, seed=1)
+    st = inst.start.cuda()
+    torch.cuda.synchronize()
+    with NativeMPPI(horizon=30, num_samples=512, grid_size=128, resolution=0.5) as pl:
+        pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+        feed = lambda mode, us: pl._lib.bn_mppi_debug_cadence(pl._h, mode, us)
+        assert pl.overlap_mode() == 0
+        assert feed(0, 8.0) == 0 and feed(0, 8.1) == 1          # two windows seen: the next long batch looks at one stream
+        assert feed(1, 12.3) == 0 and pl.overlap_mode() == 0     # slower: stay
+        assert feed(0, 9.0) == 0 and pl.overlap_mode() == 0
+        feed(0, 21.0)                                            # 2.6 x the best overlapped cadence and well above one stream's: a co-tenant
+        assert pl.overlap_mode() == 1
+        for i in range(255):
+            assert feed(1, 12.5) == 0 and pl.overlap_mode() == 1
+        assert feed(1, 12.5) == 1                                # 256 windows on one stream: look at the overlapped mode again
+        feed(0, 20.0)
+        assert pl.overlap_mode() == 1                            # still there
+        for i in range(256):
+            feed(1, 12.5)
+        feed(0, 8.2)                                             # gone
+        assert pl.overlap_mode() == 0
+        # batches run and give the same results whatever mode the tuner picks
+        pl.solve_n_async_device(200, st.data_ptr()); pl.sync()
+        a = pl.get_mean()
+        feed(0, 30.0)
+        assert pl.overlap_mode() == 1
+        pl.set_mean(None)
+    with NativeMPPI(horizon=30, num_samples=512, grid_size=128, resolution=0.5) as p2, \
+         NativeMPPI(horizon=30, num_samples=512, grid_size=128, resolution=0.5, overlap=False) as p3:
+        for q in (p2, p3):
+            q.set_map(inst.risk.numpy()); q.set_goal(inst.goal.numpy())
+        assert p3.overlap_mode() == 3
+        p2._lib.bn_mppi_debug_cadence(p2._h, 0, 8.0); p2._lib.bn_mppi_debug_cadence(p2._h, 1, 9.0); p2._lib.bn_mppi_debug_cadence(p2._h, 0, 40.0)
+        assert p2.overlap_mode() == 1                            # by choice: its batches take the one-stream path
+        p2.solve_n_async_device(200, st.data_ptr()); p2.sync()
+        p3.solve_n_async_device(200, st.data_ptr()); p3.sync()
+        assert np.array_equal(p2.get_mean(), p3.get_mean()) and np.array_equal(p2.get_mean(), a)
+        assert np.array_equal(p2.states(), p3.states())
+    with NativeMPPI(horizon=30, num_samples=512, grid_size=128, resolution=0.5) as p4:
+        p4.set_map(inst.risk.numpy()); p4.set_goal(inst.goal.numpy())
+        p4.solve_n_async_device(8, st.data_ptr())
+        _capi.check(p4._lib.bn_mppi_debug_expire_wait(p4._h))
+        p4.sync()
+        assert p4.recovery_count() == 1 and p4.overlap_mode() == 2
