@@ -2,7 +2,7 @@
 started and ended (chip-wide 100 MHz clock), how many cycles it ran, and where (XCC / SE / CU from HW_ID).
     BN_BS=60,64 BN_XCD_PACK=0 python tools/block_trace.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

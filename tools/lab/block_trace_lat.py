@@ -2,7 +2,7 @@
 --timing timing): entry / exit of every workgroup on the chip-wide clock (the 16 rollout workgroups and the aux workgroup that runs the
 previous solve's tail).  What a launch's end waits for, and how long after it the next launch of the same stream enters."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

@@ -2,7 +2,7 @@
 python tools/stamps.py build): start / end of every workgroup on the chip-wide clock, rows kept by solve parity.
     BN_BS=40,64 python tools/block_trace_overlap.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

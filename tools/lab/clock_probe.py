@@ -2,7 +2,7 @@
 cycle counter and the 100 MHz wall clock behind its first chunk and behind its last step; their ratio is the clock the chain ran at.
 Round 4: 2.38-2.43 GHz -- the kernel's waves are not slowed by a power state.  BN_VARIANT=<name> picks the library."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

@@ -1,7 +1,7 @@
 """Is the sporadic 2x-slower timed loop host-bound?  Time the enqueue call (returns when all launches are queued)
 against the whole loop, a few trials in one process."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from benchnav_amd import NativeMPPI, synth
 inst = synth.make_instance(256, seed=0)

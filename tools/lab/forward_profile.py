@@ -1,5 +1,5 @@
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 from helpers import load_case, mppi_for_fixture
 fx = load_case("c2")

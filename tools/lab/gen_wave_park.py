@@ -1,6 +1,6 @@
 """Regenerate benchnav_amd/csrc/wave_park.h for a register-block base:  python tools/gen_wave_park.py 68   (block = v[base .. 127])"""
 import os, re, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 base = int(sys.argv[1]); n = (128 - base) & ~3
 path = os.path.join(ROOT, "benchnav_amd", "csrc", "wave_park.h")
 s = open(path).read()

@@ -1,7 +1,7 @@
 """Would splitting a many-instance launch into instance groups on separate streams raise throughput?  G independent handles of
 64/G instances each (private streams), n dependent solves enqueued on each, all running at once; against one 64-instance handle."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from benchnav_amd import NativeMPPI, synth

@@ -1,6 +1,6 @@
 """Resident rollout workgroups per CU as the HIP runtime computes it (timing build)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, torch
 from benchnav_amd import build as b

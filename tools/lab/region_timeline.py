@@ -1,7 +1,7 @@
 """Where bench.py's K=20 timed region spends its fixed cost: host stamps (call, enqueue done, sync done) and a HIP event pair
 (first packet .. behind the tail) for the closing synchronisation variants.  Env: BN_JOIN=1 restores the cross-stream join."""
 import os, sys, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from benchnav_amd import NativeMPPI, synth

@@ -2,7 +2,7 @@
 the runtime's default wait against hipDeviceScheduleSpin (hipSetDeviceFlags) and against an empty region (sync, sync) and a region
 holding one empty-ish kernel (torch's fill of 1 element): what the runtime alone needs for launch + completion."""
 import ctypes, os, sys, time, statistics
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from benchnav_amd import NativeMPPI, synth

@@ -1,7 +1,7 @@
 """In-kernel phase timing (s_memtime stamps) of the rollout and finish kernels; needs a -DBN_TIMING build:
    python tools/stamps.py build   (here)      python tools/stamps.py   (GPU box)"""
 import os, sys, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ.get("BN_VARIANT", "timing"))
 if len(sys.argv) > 1 and sys.argv[1] == "build":

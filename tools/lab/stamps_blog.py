@@ -1,7 +1,7 @@
 """Consumer B against the chain in the overlapped steady state (timing build: tools/build_variant_fast.py --timing <name>): when the chain
 started chunks 3 / 7 / the last ones, and when consumer B had the slots below 16 / 32 / 44 / 48 behind it.  BN_VARIANT selects the library."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

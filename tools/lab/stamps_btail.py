@@ -1,7 +1,7 @@
 """Consumer B's looks over the end of the chain (timing build: tools/build_variant_fast.py --timing <name>): every look from slot 36 on as
 (time after the chain's start, slot reached, slots found), next to the chain's chunk starts and its last step.  BN_VARIANT selects the library."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

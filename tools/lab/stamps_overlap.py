@@ -1,7 +1,7 @@
 """Timeline of the overlapped steady state (timing build: python tools/stamps.py build): wall-clock stamps (100 MHz, chip-wide)
 of workgroup 0 of two consecutive launches, kept by solve parity."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

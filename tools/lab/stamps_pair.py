@@ -2,7 +2,7 @@
 behind the cost, partial rows out -- of workgroup 0 of solve n-2 (same stream as n), n-1 and n, relative to the entry of solve n-1.
 Answers: how long before its predecessor's rows is a launch resident, and what does its period hang on.  BN_VARIANT selects the library."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

@@ -1,7 +1,7 @@
 """How often does a waiting launch look?  Timing build: the cycle counter at the end of every granule poll of workgroup 0's three polling
 waves (chain, wave 2, wave 3) in the overlapped steady state -- the last 16 polls before the rows were seen.  BN_VARIANT selects the library."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b

@@ -1,6 +1,6 @@
 """In-kernel phase timing of the sampled-slip kernels (config 3); needs the -DBN_TIMING build of tools/stamps.py."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import ctypes as C, numpy as np, torch
 from benchnav_amd import build as b
