@@ -654,7 +654,7 @@ void tune_record(bn_mppi *h, int mode, double us)
     t.windows[mode] += 1;
     if (mode == t.chosen) {
         if (t.chosen == 0) {
-            if (t.best[1] == 0) { if (t.windows[0] >= 2) t.explore = 1; }                          // never seen the other mode: look once
+            if (t.best[1] == 0) { if (t.windows[0] >= 64) t.explore = 1; }                         // never seen the other mode: look once (4096 launches in)
             else if (us > 1.5 * t.best[0]) {
                 if (us > 1.15 * t.best[1]) { t.chosen = 1; t.switches += 1; t.since_explore = 0; }   // somebody else is on the device: the waiting workgroups hurt
                 else t.explore = 1;
@@ -1997,9 +1997,18 @@ int bn_mppi_solve_n_async(bn_mppi_t *h, int32_t n, const float *states, bn_mem_k
     // device-scope loads after its wait (64 instances: 29.6 -> 24.8 us per control step).
     const bool overlap = (h->lat_kernel || h->role_overlap || h->ticket_overlap) && h->n_streams > 1 && (h->d_Xalt[0] || h->p.lean) && n >= 3 && states_where == BN_MEM_DEVICE &&
                          noise != BN_NOISE_HOST_KT2 && !(h->cfg.flags & (BN_FLAG_PROFILE | BN_FLAG_NO_OVERLAP)) && !h->shard_pending && !h->overlap_off;
-    // which mode this batch runs in: the handle's choice, or -- once -- the other one, for a look (tune_record)
+    // which mode this batch runs in: the handle's choice, or -- for its first 192 launches, once -- the other one, for a look (tune_record)
     int mode = overlap ? h->tune.chosen : 1;
-    if (overlap && h->tune.explore && n >= 128 && !h->in_episode) mode = 1 - h->tune.chosen;
+    if (overlap && h->tune.explore && n >= 128 && !h->in_episode && !h->replaying) {
+        const int32_t ring = eps ? eps_ring : 1;
+        const int32_t prefix = ((192 + ring - 1) / ring) * ring;       // (a whole number of turns of the caller's noise ring: the rest starts at block 0 again)
+        if (n > prefix + 2) {
+            if (int rc = bn_mppi_solve_n_async(h, prefix, states, states_where, eps, noise, eps_ring, eps_stride)) return rc;
+            h->tune.explore = 0;                                        // (looked, whether or not the windows were conclusive)
+            return bn_mppi_solve_n_async(h, n - prefix, states, states_where, eps, noise, eps_ring, eps_stride);
+        }
+        mode = 1 - h->tune.chosen;
+    }
     if (mode != h->run_mode) h->ov_sample.valid = false;
     h->run_mode = mode;
     bool mine = overlap && mode == 0;

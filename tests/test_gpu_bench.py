@@ -34,6 +34,18 @@ def test_single_rank_line():
     assert out["sustained"]["value"] > 20000
 
 
+def test_the_line_carries_the_reference_boundarys_own_figure():
+    """`dropin_forward` / `value_dropin_forward`: benchnav_amd.MPPI.forward(state) + first_action() once per control step with the state
+    living on the host (test/test_mppi.py:174-181) -- one launch per forward, the host-paced loop on, the mailbox value IS action_seq[0],
+    and faster than the same loop without the opt-in."""
+    out = _bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-batched"])
+    d = out["dropin_forward"]
+    assert out["value_dropin_forward"] == d["value"] and d["unit"] == "control steps/s"
+    assert d["launches_per_forward"] == 1 and d["host_loop"] is True and d["first_action_equals_action_seq0"] is True
+    assert d["value"] > 35000 and d["us_per_step"] < d["without_host_loop"]["us_per_step"] < d["with_cpu_readback"]["us_per_step"] + 10
+    assert abs(sum(d["split_us"].values()) - d["us_per_step"]) < 0.5
+
+
 def test_gpus_2_self_launches_two_ranks_on_the_device():
     import torch
     share = {} if torch.cuda.device_count() >= 2 else {"BENCH_SHARE_GPU": "1", "BENCH_DIST_BACKEND": "gloo"}

@@ -426,7 +426,9 @@ def test_overlap_mode_getter_and_the_tuners_policy():
         pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
         feed = lambda mode, us: pl._lib.bn_mppi_debug_cadence(pl._h, mode, us)
         assert pl.overlap_mode() == 0
-        assert feed(0, 8.0) == 0 and feed(0, 8.1) == 1          # two windows seen: the next long batch looks at one stream
+        for i in range(63):
+            assert feed(0, 8.0 + 0.001 * i) == 0
+        assert feed(0, 8.1) == 1                                 # 64 windows seen (4096 launches): the next long batch looks at one stream
         assert feed(1, 12.3) == 0 and pl.overlap_mode() == 0     # slower: stay
         assert feed(0, 9.0) == 0 and pl.overlap_mode() == 0
         feed(0, 21.0)                                            # 2.6 x the best overlapped cadence and well above one stream's: a co-tenant
