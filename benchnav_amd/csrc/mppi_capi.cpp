@@ -230,7 +230,7 @@ struct bn_mppi {
     bool hp_enabled = false;
     hipStream_t hp_stream[2] = {};   // [0] = xstream[0], [1] = xstream[1] (created for this mode); the launches alternate
     hipEvent_t hp_ev[2] = {};        // recorded behind every prelaunch; the handle's stream waits for it when the request is posted
-    unsigned long long *h_req = nullptr, *d_req = nullptr;         // pinned: kSlots x 8 request granules + (at [kSlots * 8]) the give-up word
+    unsigned long long *h_req = nullptr, *d_req = nullptr;         // pinned: kSlots x 8 request granules, then 16 status words (acknowledgements, "gave up" per slot)
     unsigned long long *req_bar = nullptr;                         // the request granules in DEVICE memory the host writes through the BAR (bar_alloc), or null
     unsigned long long *d_req_dev = nullptr;                       // device: kSlots x 8, republished by the launches' tail workgroups
     uint32_t hp_seq = 0;             // request tags, unique per prelaunch
@@ -448,7 +448,7 @@ void hp_write_request(bn_mppi *h, int slot, uint32_t tag, const float st[3], con
 // The tail workgroup of the launch with this tag gave up waiting for the host (~50 ms) and said so: the launch has ended, nothing happened.
 bool hp_gave_up(const bn_mppi *h, uint32_t tag)
 {
-    return tag != 0 && h->h_req && __atomic_load_n(h->h_req + (size_t)kSlots * 8, __ATOMIC_ACQUIRE) == (((unsigned long long)tag << 32) | 2ull);
+    return tag != 0 && h->h_req && __atomic_load_n(h->h_req + (size_t)kSlots * 8 + 8 + (tag % kSlots), __ATOMIC_ACQUIRE) == (((unsigned long long)tag << 32) | 2ull);
 }
 
 // A launch that still waits for its state is told to leave -- it has touched nothing but its own LDS -- and the host's bookkeeping
@@ -1060,7 +1060,7 @@ int bn_mppi_create(const bn_mppi_config *cfg, bn_mppi_t **out)
         (void)hipGetLastError();
         (void)hipMemset(probe, 0, 2 * sizeof(int));
         if (ok && found) {
-            const size_t words = (size_t)kSlots * 8 + 8;
+            const size_t words = (size_t)kSlots * 8 + 16;      // request slots | [0] spare, [1..4] acknowledgements, [7] create's echo | [8..11] "gave up" per slot
             ok = hipHostMalloc((void **)&h->h_req, words * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess &&
                  hipHostGetDevicePointer((void **)&h->d_req, h->h_req, 0) == hipSuccess;
             if (ok) std::memset(h->h_req, 0, words * sizeof(unsigned long long));
