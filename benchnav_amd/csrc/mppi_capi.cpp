@@ -1661,7 +1661,7 @@ static int hp_post(bn_mppi *h, const float st[3], float *out_device)
     h->self_used = true;
     h->hp_gran_valid = true;
     // whatever the caller enqueues on the handle's stream from here on is ordered behind this solve's launch (its outputs)
-    { BN_HP_TICK(1); BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[h->hp_q], 0)); }
+    if (!exp_env("BN_HP_NO_WAIT")) { BN_HP_TICK(1); BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[h->hp_q], 0)); }      // (the switch: experiment builds, tools/stamps_forward.py)
     return BN_OK;
 }
 

@@ -11,7 +11,8 @@ from benchnav_amd import NativeMPPI, synth, _capi
 inst = synth.make_instance(256, seed=0)
 ref = os.environ.get("BN_REF") == "1"
 paced = os.environ.get("BN_PACED") == "1"
-pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, stream=0, reference_order=ref, host_paced=paced)
+_side = torch.cuda.Stream() if os.environ.get("BN_SIDE_STREAM") == "1" else None      # the planner on a stream of torch's other than the default one
+pl = NativeMPPI(horizon=50, num_samples=1024, grid_size=256, resolution=0.5, stream=(_side.cuda_stream if _side else 0), reference_order=ref, host_paced=paced)
 assert pl.host_paced() == paced
 pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
 stamps = torch.zeros(1024, dtype=torch.int64, device="cuda")
@@ -45,7 +46,7 @@ for rep in range(60):
     rows.append(stamps.cpu().numpy().astype(np.float64).copy())
 host = np.median(np.array(host), axis=0) * 1e6
 # a loop without synchronisation: the rate the drop-in boundary runs at
-n = 2000
+n = int(os.environ.get("BN_LOOP", "2000"))
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(n):
     fwd(h, sptr, None, 0, None); lib.bn_mppi_first_action(h, 0, fap)
