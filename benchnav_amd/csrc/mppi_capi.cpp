@@ -1627,9 +1627,9 @@ static bool hp_prelaunch(bn_mppi *h)
     g_hpc[2].ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - bn_t_pre).count(); g_hpc[2].n += 1;
 #endif
     hipError_t e;
-    { BN_HP_TICK(3); e = p.ref_order ? bn::launch_rollout_lat_host_ref(p, h->hp_stream[q]) : bn::launch_rollout_lat_host(p, h->hp_stream[q]); }
+    // (the completion event goes out with the launch: one runtime call)
+    { BN_HP_TICK(3); e = p.ref_order ? bn::launch_rollout_lat_host_ref(p, h->hp_stream[q], h->hp_ev[q]) : bn::launch_rollout_lat_host(p, h->hp_stream[q], h->hp_ev[q]); }
     if (e != hipSuccess) { (void)hipGetLastError(); h->hp_enabled = false; return false; }
-    { BN_HP_TICK(4); if (hipEventRecord(h->hp_ev[q], h->hp_stream[q]) != hipSuccess) (void)hipGetLastError(); }
     h->pub[cur3] += (unsigned long long)p.nblk;
     h->tails += 1;
     h->solves += 1;
@@ -1660,8 +1660,15 @@ static int hp_post(bn_mppi *h, const float st[3], float *out_device)
     h->tail_pending = false; h->prev_published = false; h->last_batch_overlapped = false;
     h->self_used = true;
     h->hp_gran_valid = true;
-    // whatever the caller enqueues on the handle's stream from here on is ordered behind this solve's launch (its outputs)
-    if (!exp_env("BN_HP_NO_WAIT")) { BN_HP_TICK(1); BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[h->hp_q], 0)); }      // (the switch: experiment builds, tools/stamps_forward.py)
+    return BN_OK;
+}
+
+// Whatever the caller enqueues on the handle's stream from here on is ordered behind the posted solve's launch (its outputs).  Issued
+// BEHIND the next solve's prelaunch: that launch needs every microsecond of head start it can get (it has to be through its prologue when
+// the host comes back with the next state), this call only has to be made before the caller gets control back.
+static int hp_order_outputs(bn_mppi *h, int q)
+{
+    if (!exp_env("BN_HP_NO_WAIT")) { BN_HP_TICK(1); BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[q], 0)); }      // (the switch: experiment builds, tools/stamps_forward.py)
     return BN_OK;
 }
 
@@ -1681,9 +1688,10 @@ static int forward_impl(bn_mppi_t *h, const float *states_device, const float *s
     if (paced && h->hp_armed) {                        // the loop's steady state: the launch is there and waits for exactly this
         BN_BIND(h);
         if (int rc = self_check(h)) return rc;
+        const int q_posted = h->hp_q;
         if (int rc = hp_post(h, state_host, out_device)) return rc;
         (void)hp_prelaunch(h);                         // ... and the next one goes out while this one runs
-        return BN_OK;
+        return hp_order_outputs(h, q_posted);
     }
     {
         BN_BIND(h);

@@ -961,12 +961,19 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         S = ld<AGENT>(p.stats_prev + b * 2 + 1);
         __syncthreads();
     } else {
-        merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
+        if constexpr (SELF) {
+            // No tail in front of this one (a synchronous forward(): every earlier tail was ordered before the launch by the stream): the
+            // first control goes to the host's mailbox at once -- by the two threads that merged its columns, each its own, in front of the
+            // barrier the other waves' columns are waited for at -- and before the wait for the costs, the X* rollout and the weights.
+            merge_partials<NT, AGENT, BIG, false, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
+            if (!p.have_prev && p.mail != nullptr && nblk <= 64 && tid < 2) store_granule_host(p.mail + 2 * b + tid, us[tid], (uint32_t)p.tail_solve + 1u);
+            __syncthreads();
+        } else {
+            merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
+        }
     }
-    // No tail in front of this one (a synchronous forward(): every earlier tail was ordered before the launch by the stream): the first
-    // control goes to the host's mailbox at once -- before the wait for the costs, the X* rollout and the weights.
-    const bool mail_early = SELF && !p.have_prev && p.mail != nullptr;
-    if (mail_early && tid == 0) {
+    const bool mail_early = SELF && !p.have_prev && p.mail != nullptr && (p.tail_merged || nblk <= 64);
+    if (mail_early && p.tail_merged && tid == 0) {
         store_granule_host(p.mail + 2 * b, us[0], (uint32_t)p.tail_solve + 1u);
         store_granule_host(p.mail + 2 * b + 1, us[1], (uint32_t)p.tail_solve + 1u);
     }

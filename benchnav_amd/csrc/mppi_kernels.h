@@ -174,8 +174,8 @@ int rollout_blocks_per_cu(const SolveParams &p);   // runtime's occupancy answer
 
 hipError_t launch_rollout(const SolveParams &p, EpsMode mode, hipStream_t s);
 hipError_t launch_rollout_lat_self(const SolveParams &p, EpsMode mode, hipStream_t s);   // the one-launch latency kernel (rollout_lat.inc mode 1: the solve's own tail in the launch)
-hipError_t launch_rollout_lat_host(const SolveParams &p, hipStream_t s);       // the host-paced latency kernel (Philox noise), rollout_lat_host.hip
-hipError_t launch_rollout_lat_host_ref(const SolveParams &p, hipStream_t s);   // ... in the reference's operation order
+hipError_t launch_rollout_lat_host(const SolveParams &p, hipStream_t s, hipEvent_t stop);       // the host-paced latency kernel (Philox noise), rollout_lat_host.hip
+hipError_t launch_rollout_lat_host_ref(const SolveParams &p, hipStream_t s, hipEvent_t stop);   // ... in the reference's operation order
 hipError_t launch_finish(const SolveParams &p, hipStream_t s);
 // K-sharded solve: merge of all shards' partial rows -> ustar_cur, stats_cur, ustar, mean.  group_rows: 64 x (2 + 2T) floats, ticket: one zeroed int
 hipError_t launch_shard_merge(const SolveParams &p, float *group_rows, int *ticket, hipStream_t s);

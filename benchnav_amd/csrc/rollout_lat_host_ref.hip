@@ -7,5 +7,11 @@
 #include "rollout_lat.inc"
 
 namespace bn {
-hipError_t launch_rollout_lat_host_ref(const SolveParams &p, hipStream_t s) { return launch_lat_e<kEpsPhilox>(p, s); }
+hipError_t launch_rollout_lat_host_ref(const SolveParams &p, hipStream_t s, hipEvent_t stop)
+{
+    g_lat_stop_event = stop;                           // (recorded behind the kernel by the launch itself: rollout_lat.inc)
+    const hipError_t e = launch_lat_e<kEpsPhilox>(p, s);
+    g_lat_stop_event = nullptr;
+    return e;
+}
 }  // namespace bn
