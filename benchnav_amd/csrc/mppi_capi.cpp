@@ -1386,6 +1386,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             h->ep_len += 1;
         }
         p.wave_kernel = (h->wave_kernel && !h->in_episode) ? 1 : 0;
+        if (p.wave_kernel && p.xs == 0 && exp_env("BN_AUX_FIRST")) p.aux_first = 1;      // (experiment builds: VERDICT r5 #3)
         p.lat_kernel = h->lat_kernel ? 1 : 0;
         hipStream_t st = h->stream;
         p.flag_tail = h->d_flags + kSlots * B * bn::kFlagStride;
