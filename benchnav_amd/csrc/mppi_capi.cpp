@@ -215,7 +215,7 @@ struct bn_mppi {
     // counts finished solves, the host clock does the rest: no event, no kernel change -- over windows of 64 launches that found the
     // device backlogged at both ends, looks at the other mode once, and runs whichever is faster; it looks again when its cadence
     // degrades by half, and every 256 windows while it runs on one stream (has the co-tenant left?).
-    struct OvTune { double best[2] = {0, 0}, last[2] = {0, 0}; int chosen = 0, explore = 0; uint64_t windows[2] = {0, 0}, since_explore = 0, switches = 0; } tune;
+    struct OvTune { double best[2] = {0, 0}, last[2] = {0, 0}, ema[2] = {0, 0}; int chosen = 0, explore = 0, slow_run = 0; uint64_t windows[2] = {0, 0}, since_explore = 0, switches = 0; } tune;
     struct OvSample { bool valid = false; std::chrono::steady_clock::time_point t{}; uint32_t prog = 0, enq = 0; } ov_sample;
     int run_mode = 0;                // the mode of the batch being enqueued (0 overlapped, 1 one stream)
     // One launch per SYNCHRONOUS solve (round 6; bn_mppi_forward_async, bn_mppi_forward_state_async, bn_mppi_solve on the latency kernel):
@@ -650,18 +650,24 @@ void tune_record(bn_mppi *h, int mode, double us)
 {
     bn_mppi::OvTune &t = h->tune;
     t.last[mode] = us;
-    if (t.best[mode] == 0 || us < t.best[mode]) t.best[mode] = us;
+    t.ema[mode] = t.ema[mode] == 0 ? us : t.ema[mode] + (us - t.ema[mode]) / 8;
+    // the mode's best cadence: the minimum over windows that are not implausibly fast (one short window -- a host hiccup between two
+    // looks at the mailbox -- must not become the yardstick everything after it fails)
+    if (us >= 0.7 * t.ema[mode] && (t.best[mode] == 0 || us < t.best[mode])) t.best[mode] = us;
     t.windows[mode] += 1;
     if (mode == t.chosen) {
+        t.since_explore += 1;
+        t.slow_run = (t.best[mode] > 0 && us > 1.5 * t.best[mode]) ? t.slow_run + 1 : 0;
         if (t.chosen == 0) {
-            if (t.best[1] == 0) { if (t.windows[0] >= 64) t.explore = 1; }                         // never seen the other mode: look once (4096 launches in)
-            else if (us > 1.5 * t.best[0]) {
-                if (us > 1.15 * t.best[1]) { t.chosen = 1; t.switches += 1; t.since_explore = 0; }   // somebody else is on the device: the waiting workgroups hurt
-                else t.explore = 1;
+            if (t.best[1] == 0) { if (t.windows[0] >= 64) { t.explore = 1; t.since_explore = 0; } }      // never seen the other mode: look once (4096 launches in)
+            else if (t.slow_run >= 4) {                    // four windows in a row at 1.5 x this mode's best: somebody else is on the device
+                t.slow_run = 0;
+                if (us > 1.15 * t.best[1]) { t.chosen = 1; t.switches += 1; t.since_explore = 0; }   // ... and one stream was faster than this when last seen
+                else if (t.since_explore >= 64) { t.explore = 1; t.since_explore = 0; }
             }
-        } else if (++t.since_explore >= 256) { t.explore = 1; t.since_explore = 0; }              // has the co-tenant left?
+        } else if (t.since_explore >= 256) { t.explore = 1; t.since_explore = 0; }                 // has the co-tenant left?
     } else {                                           // a look at the other mode
-        if (t.last[t.chosen] > 0 && us < 0.9 * t.last[t.chosen]) { t.chosen = mode; t.switches += 1; t.since_explore = 0; }
+        if (t.last[t.chosen] > 0 && us < 0.9 * t.last[t.chosen]) { t.chosen = mode; t.switches += 1; t.since_explore = 0; t.slow_run = 0; }
         t.explore = 0;
     }
 }

@@ -431,7 +431,11 @@ def test_overlap_mode_getter_and_the_tuners_policy():
         assert feed(0, 8.1) == 1                                 # 64 windows seen (4096 launches): the next long batch looks at one stream
         assert feed(1, 12.3) == 0 and pl.overlap_mode() == 0     # slower: stay
         assert feed(0, 9.0) == 0 and pl.overlap_mode() == 0
-        feed(0, 21.0)                                            # 2.6 x the best overlapped cadence and well above one stream's: a co-tenant
+        assert feed(0, 3.0) == 0 and feed(0, 8.0) == 0 and pl.overlap_mode() == 0   # one implausibly short window does not become the yardstick
+        for i in range(3):
+            feed(0, 21.0)                                        # 2.6 x the best overlapped cadence and well above one stream's ...
+            assert pl.overlap_mode() == 0
+        feed(0, 21.0)                                            # ... four windows in a row: a co-tenant
         assert pl.overlap_mode() == 1
         for i in range(255):
             assert feed(1, 12.5) == 0 and pl.overlap_mode() == 1
@@ -445,7 +449,8 @@ def test_overlap_mode_getter_and_the_tuners_policy():
         # batches run and give the same results whatever mode the tuner picks
         pl.solve_n_async_device(200, st.data_ptr()); pl.sync()
         a = pl.get_mean()
-        feed(0, 30.0)
+        for i in range(4):
+            feed(0, 30.0)
         assert pl.overlap_mode() == 1
         pl.set_mean(None)
     with NativeMPPI(horizon=30, num_samples=512, grid_size=128, resolution=0.5) as p2, \
@@ -453,7 +458,9 @@ def test_overlap_mode_getter_and_the_tuners_policy():
         for q in (p2, p3):
             q.set_map(inst.risk.numpy()); q.set_goal(inst.goal.numpy())
         assert p3.overlap_mode() == 3
-        p2._lib.bn_mppi_debug_cadence(p2._h, 0, 8.0); p2._lib.bn_mppi_debug_cadence(p2._h, 1, 9.0); p2._lib.bn_mppi_debug_cadence(p2._h, 0, 40.0)
+        p2._lib.bn_mppi_debug_cadence(p2._h, 0, 8.0); p2._lib.bn_mppi_debug_cadence(p2._h, 1, 9.0)
+        for i in range(4):
+            p2._lib.bn_mppi_debug_cadence(p2._h, 0, 40.0)
         assert p2.overlap_mode() == 1                            # by choice: its batches take the one-stream path
         p2.solve_n_async_device(200, st.data_ptr()); p2.sync()
         p3.solve_n_async_device(200, st.data_ptr()); p3.sync()
