@@ -32,6 +32,9 @@ Extra objects on the line:
   cpu_baseline  the PyTorch-CPU port of the reference (oracle/torch_port.py) timed on this host (N = 1 only)
   batched       64 instances per launch (config 4's per-node batch on one GPU): the regime where the HBM roofline is
                 meaningful; with its lean-mode line (no trajectory dump) beside the full-API one
+  dropin_forward / value_dropin_forward   the reference's own boundary (test/test_mppi.py:174-181): benchnav_amd.MPPI.forward(state) +
+                first_action() once per control step, the state living on the host and changing every step -- with the time split
+                (forward call, first-action wait, host environment step), the same loop without `host_loop` and with `U[0].cpu()`
 """
 from __future__ import annotations
 
@@ -439,7 +442,7 @@ def main():
         out["lean"] = {"value": 1.0 / s_l, "unit": "solves/s", "ms_per_step": s_l * 1e3,
                        "note": "BN_FLAG_LEAN: _state_seq_batch not materialised; get_top_samples re-rolls the requested rows bit-identically",
                        "roofline": roof(by_l, ms_l, f"rollout_{a.noise}_B1_lean", by_lw)}
-        # ---- BN_FLAG_REFERENCE_ORDER: the transit in the reference's own operation order (two launches per solve, one stream) ----
+        # ---- BN_FLAG_REFERENCE_ORDER: the transit in the reference's own operation order (same kernels, one launch per solve: `launches_per_solve`) ----
         plo = make_planner(inst, reference_order=True)
         s_o, ms_o = leg(plo, state_dev, eps_ring, max(300, a.steps))
         assert plo.arithmetic() == "reference_order"
