@@ -1276,14 +1276,16 @@ __device__ __forceinline__ void ticket_merge(const SolveParams &p, int b, int bl
 // Producer: the clamped perturbed controls of steps t and t+1 (t even) of this lane's rollout,
 //   u = clamp(mean + sigma * eps, u_min, u_max)          mppi.py:152-157
 // written to the LDS control tile (and to HBM when _perturbed_action_seqs is materialised).
-template <int EPS, bool STORE_U>
+// FRESH: the Philox round keys are derived at the call (philox_eps_pair<true>) instead of living in scalar registers across the caller's
+// loop -- the role kernel (round 6): its loops reload spilled scalars with v_readlane, a vector instruction each.
+template <int EPS, bool STORE_U, bool FRESH = false>
 __device__ __forceinline__ void produce_pair(const SolveParams &p, const float *__restrict__ eps, int b, int kk, int t,
                                              uint64_t solve, const float *ml, float *Ul, float *Ub, size_t Kp, int lane)
 {
     float e[4];
     const int t1 = min(t + 1, p.T - 1);
     if (EPS == kEpsPhilox) {
-        philox_eps_pair(p.seed, solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), e);
+        philox_eps_pair<FRESH>(p.seed, solve, (uint32_t)b, (uint32_t)(kk + p.k0), (uint32_t)(t >> 1), e);
     } else if (EPS == kEpsKT2) {
         const float *row = eps + ((size_t)b * p.K + kk) * p.T * 2;
         const float2 v0 = *reinterpret_cast<const float2 *>(row + 2 * t);

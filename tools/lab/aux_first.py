@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 from benchnav_amd import build as b
-b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_exp.so")
+b.LIB_PATH = os.path.join(ROOT, "tools", "_ablate", "lib_%s.so" % os.environ.get("BN_TOOL_LIB", "exp")) if os.environ.get("BN_TOOL_LIB", "exp") != "main" else b.LIB_PATH
 from benchnav_amd import NativeMPPI, synth
 inst = synth.make_instance(256, seed=0)
 B = int(os.environ.get("BN_BS", "256"))
@@ -21,5 +21,5 @@ for overlap in (True, False):
         dt = (time.perf_counter() - t0) / 300; pl.sync()
         best = dt if best is None else min(best, dt)
     h = hashlib.sha256(pl.get_mean(0).tobytes() + pl.weights(B - 1).tobytes()).hexdigest()[:12]
-    print(f"aux_first={'BN_AUX_FIRST' in os.environ} overlap={overlap}: {best * 1e6:.2f} us per launch, outputs {h}", flush=True)
+    print(f"lib={os.environ.get('BN_TOOL_LIB', 'exp')} B={B} aux_first={'BN_AUX_FIRST' in os.environ} overlap={overlap}: {best * 1e6:.2f} us per launch, outputs {h}", flush=True)
     pl.close()
