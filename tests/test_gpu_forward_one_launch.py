@@ -143,3 +143,41 @@ def test_drop_in_class_takes_a_host_state_by_value():
         outs[where] = seq
     for (u0, x0, w0), (u1, x1, w1) in zip(outs["cpu"], outs["cuda"]):
         assert np.array_equal(u0, u1) and np.array_equal(x0, x1) and np.array_equal(w0, w1)
+
+
+def test_forward_entry_points_on_handles_the_latency_kernel_does_not_serve():
+    """The role kernel (24 instances), the ticket path (K = 8192) and the one-wave kernel (300 instances): bn_mppi_forward_async and
+    bn_mppi_forward_state_async (states staged and uploaded there) keep their two launches and agree with each other and with the
+    BN_FLAG_NO_PIPELINE chain, first action and caller's block included."""
+    import torch
+    from benchnav_amd import NativeMPPI, synth
+    G = 128
+    inst = synth.make_instance(G, seed=8)
+    for K, T, B in ((1024, 30, 24), (8192, 25, 1), (256, 20, 300)):
+        states = [(np.tile(inst.start.numpy(), (B, 1)) + 0.1 * i + 0.01 * np.arange(B)[:, None]).astype(np.float32) for i in range(3)]
+        dstates = [torch.from_numpy(s).cuda() for s in states]
+        torch.cuda.synchronize()
+        n_out = B * (T * 2 + (T + 1) * 3)
+        res = {}
+        for mode in ("device", "host", "two"):
+            with NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, num_instances=B, shared_map=True, seed=4, pipeline=(mode != "two")) as pl:
+                pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
+                assert pl.launches_per_forward() == 2 and not pl.host_paced()
+                outs = []
+                for i in range(3):
+                    out = torch.zeros(n_out, device="cuda")
+                    torch.cuda.synchronize()
+                    if mode == "host":
+                        pl.forward_state_async(states[i], None, 0, out.data_ptr())
+                    else:
+                        pl.forward_async_device(dstates[i].data_ptr(), None, 0, out.data_ptr())
+                    fa = pl.first_action(B - 1).copy()
+                    pl.sync()
+                    o = out.cpu().numpy()
+                    assert np.array_equal(fa, o[:B * T * 2].reshape(B, T, 2)[B - 1, 0])
+                    outs.append((o, pl.weights(B - 1), pl.costs(0)))
+                res[mode] = outs
+        for mode in ("device", "host"):
+            for i in range(3):
+                for j in range(3):
+                    assert np.array_equal(res[mode][i][j], res["two"][i][j]), (K, B, mode, i, j)

@@ -10,9 +10,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _planner(K, T, G, inst, paced, **kw):
+def _planner(K, T, G, inst, paced, resolution=0.5, **kw):
     from benchnav_amd import NativeMPPI
-    pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=0.5, seed=9, stream=0, host_paced=paced, **kw)
+    pl = NativeMPPI(horizon=T, num_samples=K, grid_size=G, resolution=resolution, seed=9, stream=0, host_paced=paced, **kw)
     pl.set_map(inst.risk.numpy()); pl.set_goal(inst.goal.numpy())
     return pl
 
@@ -50,16 +50,18 @@ def _run(pl, states, T, events=None, sleep_at=(), sleep_s=0.0):
     return [o.cpu().numpy() for o in outs], acts, (pl.states(), pl.costs(), pl.weights(), pl.get_mean())
 
 
-@pytest.mark.parametrize("K,T,ref_order,store_u", [(1024, 50, False, False), (1024, 50, True, False), (512, 33, False, True), (128, 20, False, False), (100, 7, True, True)],
-                         ids=["c2", "c2-ref", "K512-U", "c1", "ragged-ref-U"])
-def test_host_paced_loop_is_bit_identical_to_the_one_launch_loop(K, T, ref_order, store_u):
+@pytest.mark.parametrize("K,T,ref_order,store_u,extra", [(1024, 50, False, False, {}), (1024, 50, True, False, {}), (512, 33, False, True, {}), (128, 20, False, False, {}),
+                                                         (100, 7, True, True, {}), (1024, 50, False, False, {"lean": True}), (512, 40, False, False, {"resolution": 0.3}),
+                                                         (512, 40, True, True, {"resolution": 0.3})],
+                         ids=["c2", "c2-ref", "K512-U", "c1", "ragged-ref-U", "lean", "res0.3", "res0.3-ref-U"])
+def test_host_paced_loop_is_bit_identical_to_the_one_launch_loop(K, T, ref_order, store_u, extra):
     from benchnav_amd import synth
     G = 256
-    inst = synth.make_instance(G, seed=3)
+    inst = synth.make_instance(G, seed=3, resolution=extra.get("resolution", 0.5))
     states = _states(inst, 14, jump_at=(6,))
     res = {}
     for paced in (True, False):
-        with _planner(K, T, G, inst, paced, reference_order=ref_order, store_controls=store_u) as pl:
+        with _planner(K, T, G, inst, paced, reference_order=ref_order, store_controls=store_u, **extra) as pl:
             assert pl.host_paced() == paced
             res[paced] = _run(pl, states, T)
             assert pl.solve_count() == len(states)
