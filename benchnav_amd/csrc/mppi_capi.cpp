@@ -1418,6 +1418,7 @@ static int solve_impl(bn_mppi_t *h, const float *states, bn_mem_kind states_wher
             p.wait_tail_self = h->tails;
             h->tails += 1;
             p.out_copy_self = h->self_out_copy;
+            if (exp_env("BN_NO_EARLY_MAIL")) p.no_early_mail = 1;      // (experiment builds)
             if (h->inline_state && p.B == 1) { p.state_inline = 1; p.sv0 = h->inline_state[0]; p.sv1 = h->inline_state[1]; p.sv2 = h->inline_state[2]; }
             h->self_used = true;
             h->self_tail_launched = true;
@@ -1605,6 +1606,7 @@ static bool hp_prelaunch(bn_mppi *h)
     if (!p.store_u) p.U = nullptr;
     else if (xi && h->d_Ualt[0]) p.U = h->d_Ualt[0];
     p.host_paced = 1;
+    if (exp_env("BN_NO_EARLY_MAIL")) p.no_early_mail = 1;      // (experiment builds)
     p.sv0 = h->hp_prev_state[0]; p.sv1 = h->hp_prev_state[1]; p.sv2 = h->hp_prev_state[2];
     p.spec_extra = h->hp_extra;
     const uint32_t tag = h->hp_seq + 1;

@@ -927,6 +927,26 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         if (self_gran) {
             const unsigned long long *grows = gran_self + (size_t)b * nblk * PS;
             const uint32_t tag = (uint32_t)p.tail_solve + 1u;
+            const bool early = p.host_paced && !p.no_early_mail;
+            if (tid < 64 && !p.have_prev && p.mail != nullptr && early) {
+                // The host waits for U*[0] -- two columns of the sixteen rows.  Wave 0 polls just those (and the rows' statistics): a light
+                // poll sees the rows sooner than the full one (the lines that are being written are what makes a poll slow: notebook R5.4),
+                // and its lanes 0 and 1 post the first action -- merge_one: the arithmetic of merge_partials, the same bits -- before the
+                // workgroup has merged anything else.  Then it joins the full poll below (the rows are there by then).  Host-paced launches
+                // only (same box, C loop: 15.2 -> 14.6 us per step): the tail ends 1.2 us later for it, and a one-launch forward that is
+                // called back to back waits for exactly that end (22.7 -> 23.7 us per step there).
+                GranulePoll pa;
+                MergeLoads L{};
+                bool got = false;
+                for (int it = 0; it < (1 << 21) && !got; ++it) {
+                    pa.issue(grows, nblk, T, tid, tid & 1);
+                    got = __builtin_amdgcn_ballot_w64(!pa.take(tag, nblk, T, tid, tid & 1, L)) == 0;
+                }
+                if (!got) raise_wait_expired(p, nullptr, 902);
+                const float val = merge_one(L, nblk, tid);
+                if (tid < 2) store_granule_host(p.mail + 2 * b + tid, val, (uint32_t)p.tail_solve + 1u);
+                BN_SSTAMP(3);
+            }
             bool ok = false;
             for (int it = 0; it < (1 << 22) && !ok; ++it) {
                 pre = merge_issue_granules(grows, nblk, T, tid, tag, ok, tid);
@@ -966,7 +986,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
             // first control goes to the host's mailbox at once -- by the two threads that merged its columns, each its own, in front of the
             // barrier the other waves' columns are waited for at -- and before the wait for the costs, the X* rollout and the weights.
             merge_partials<NT, AGENT, BIG, false, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
-            if (!p.have_prev && p.mail != nullptr && nblk <= 64 && tid < 2) store_granule_host(p.mail + 2 * b + tid, us[tid], (uint32_t)p.tail_solve + 1u);
+            if ((!self_gran || !p.host_paced || p.no_early_mail) && !p.have_prev && p.mail != nullptr && nblk <= 64 && tid < 2) store_granule_host(p.mail + 2 * b + tid, us[tid], (uint32_t)p.tail_solve + 1u);   // (self_gran: posted above)
             __syncthreads();
         } else {
             merge_partials<NT, AGENT, BIG, true, WIDE>(part, nblk, T, us, sc, red, tid, m, S, pre_ok, pre);
@@ -977,7 +997,7 @@ __device__ __forceinline__ void finish_body(const SolveParams &p, int b, const f
         store_granule_host(p.mail + 2 * b, us[0], (uint32_t)p.tail_solve + 1u);
         store_granule_host(p.mail + 2 * b + 1, us[1], (uint32_t)p.tail_solve + 1u);
     }
-    BN_SSTAMP(3);
+    if (!self_gran || !p.host_paced || p.no_early_mail) BN_SSTAMP(3);
     // U*, the next mean, the statistics: threads j0, j0 + step, .. (all of them, or -- deferred wait -- the writing waves behind their wait)
     auto store_ustar = [&](int j0, int step, bool first) {
         if (!p.tail_merged) {

@@ -144,6 +144,7 @@ struct SolveParams {
     int req_direct;                         // req_host is DEVICE memory the host writes through the PCIe BAR: the rollout workgroups poll it themselves (no republishing hop)
     uint32_t req_tag;                       // this launch's request tag (unique per prelaunch: a cancelled launch and its successor never share one)
     int req_polls;                          // how often the tail workgroup looks for the request before it gives up (~2 us a look)
+    int no_early_mail;   // experiment switch (BN_NO_EARLY_MAIL): the self tail posts the first action behind its full merge, not from wave 0's light poll
     int aux_first;       // one-wave kernel, experiment: the aux workgroups (previous solve's tails) take the FIRST grid rows instead of the last
     int state_inline;    // the (one) instance's state travels in the kernel arguments (sv): a host loop that hands over a fresh state
     float sv0, sv1, sv2; // (three scalars, not an array: the tail workgroup works on a modified copy of this struct, and an array member
