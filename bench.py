@@ -701,6 +701,15 @@ def dropin_forward(inst, dev, n_steps):
     loop(200, False, plain)
     one = min((loop(n_steps, False, plain) for _ in range(3)), key=lambda r: r[0])
     del plain
+    acts = make("actions")                               # the opt-in's leaner form: forward() does not order torch's stream behind the solve
+    loop(200, False, acts)
+    ao = min((loop(n_steps, False, acts) for _ in range(3)), key=lambda r: r[0])
+    U, X = acts.forward(state)
+    fa = acts.first_action().clone()
+    acts.order_outputs()
+    same_ao = bool(torch.equal(fa, U[0].cpu()))
+    acts.release()
+    del acts
     lpf = int(solver._lib.bn_mppi_launches_per_forward(solver._handle))
     # cross-check of what the loop consumed: the mailbox value IS action_seq[0]
     U, X = solver.forward(state)
@@ -712,6 +721,11 @@ def dropin_forward(inst, dev, n_steps):
             "without_host_loop": {"value": 1.0 / one[0], "us_per_step": one[0] * 1e6,
                                   "split_us": {"forward_call_host": one[1] * 1e6, "first_action_wait": one[2] * 1e6, "host_env_step": one[3] * 1e6},
                                   "note": "MPPI(host_loop=False), the default: one launch per forward() (rollouts + the solve's own tail), enqueued when forward() is called"},
+            "host_loop_actions": {"value": 1.0 / ao[0], "us_per_step": ao[0] * 1e6,
+                                  "split_us": {"forward_call_host": ao[1] * 1e6, "first_action_wait": ao[2] * 1e6, "host_env_step": ao[3] * 1e6},
+                                  "first_action_equals_action_seq0": same_ao,
+                                  "note": "MPPI(host_loop='actions'), BN_FLAG_UNORDERED_OUTPUTS: forward() leaves torch's stream unordered behind the solve "
+                                          "(the stream-wait is 3-5 us of host time per step); the planner's own attributes and order_outputs() make up for it on demand"},
             "with_cpu_readback": {"value": 1.0 / rb[0], "us_per_step": rb[0] * 1e6,
                                   "note": "the unmodified reference loop: action_seq[0].cpu() instead of first_action() -- a stream synchronisation and a copy"},
             "config": {"class": "benchnav_amd.MPPI (drop-in for src/planners/local_planners/mppi.py:MPPI)", "noise": "philox", "copy_outputs": True, "host_loop": True,

@@ -28,6 +28,7 @@ BN_FLAG_LAT_KERNEL = 1024
 BN_FLAG_NO_OVERLAP = 2048
 BN_FLAG_REFERENCE_ORDER = 4096
 BN_FLAG_HOST_PACED = 8192
+BN_FLAG_UNORDERED_OUTPUTS = 16384
 BN_BUF_STATES_ALT, BN_BUF_CONTROLS_ALT = 10, 11
 BN_RISK_EXPECTED, BN_RISK_VAR, BN_RISK_CVAR = 0, 1, 2
 ABI_VERSION = 4
@@ -103,6 +104,7 @@ SYMBOLS = {
     "bn_mppi_launches_per_solve": (C.c_int32, [_H]),
     "bn_mppi_launches_per_forward": (C.c_int32, [_H]),
     "bn_mppi_host_paced": (C.c_int32, [_H]),
+    "bn_mppi_order_outputs": (C.c_int, [_H]),
     "bn_mppi_states_buffer_index": (C.c_int32, [_H]),
     "bn_mppi_fast_quotient": (C.c_int32, [_H]),
     "bn_mppi_row_pitch": (C.c_int32, [_H]),

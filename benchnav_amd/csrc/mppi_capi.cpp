@@ -230,6 +230,8 @@ struct bn_mppi {
     bool hp_enabled = false;
     hipStream_t hp_stream[2] = {};   // [0] = xstream[0], [1] = xstream[1] (created for this mode); the launches alternate
     hipEvent_t hp_ev[2] = {};        // recorded behind every prelaunch; the handle's stream waits for it when the request is posted
+    bool hp_unordered = false;       // BN_FLAG_UNORDERED_OUTPUTS: the handle's stream has not been ordered behind the latest posted solve yet ...
+    int hp_unordered_q = 0;          // ... whose launch is the latest one on this private stream (see hp_order_now)
     unsigned long long *h_req = nullptr, *d_req = nullptr;         // pinned: kSlots x 8 request granules, then 16 status words (acknowledgements, "gave up" per slot)
     unsigned long long *req_bar = nullptr;                         // the request granules in DEVICE memory the host writes through the BAR (bar_alloc), or null
     unsigned long long *d_req_dev = nullptr;                       // device: kSlots x 8, republished by the launches' tail workgroups
@@ -301,7 +303,21 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
-#define BN_BIND(h) DeviceGuard bn_guard_((h)->cfg.device_id); if (!bn_guard_.ok) return fail(BN_ERR_HIP, "hipSetDevice failed")
+#define BN_BIND_Q(h) DeviceGuard bn_guard_((h)->cfg.device_id); if (!bn_guard_.ok) return fail(BN_ERR_HIP, "hipSetDevice failed")
+
+// BN_FLAG_UNORDERED_OUTPUTS: the host-paced forward left the handle's stream unordered behind the latest posted solve (a stream-wait on a
+// pending event is 3-5 us of host time per control step, for consumers that mostly are not there).  Every entry point that enqueues on the
+// handle's stream or hands out results makes up for it here, once -- everything except the loop's own two calls.
+static inline void hp_order_now(bn_mppi *h)
+{
+    if (!h->hp_unordered) return;
+    h->hp_unordered = false;
+    if (hipStreamWaitEvent(h->stream, h->hp_ev[h->hp_unordered_q], 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->hp_stream[h->hp_unordered_q]);
+    }
+}
+#define BN_BIND(h) BN_BIND_Q(h); hp_order_now(h)
 
 size_t buffer_bytes(const bn_mppi *h, bn_buffer_id id)
 {
@@ -1677,6 +1693,7 @@ static int hp_post(bn_mppi *h, const float st[3], float *out_device)
 // the host comes back with the next state), this call only has to be made before the caller gets control back.
 static int hp_order_outputs(bn_mppi *h, int q)
 {
+    if (h->cfg.flags & BN_FLAG_UNORDERED_OUTPUTS) { h->hp_unordered = true; h->hp_unordered_q = q; return BN_OK; }    // made up for by the first call that needs it
     if (!exp_env("BN_HP_NO_WAIT")) { BN_HP_TICK(1); BN_HIP(hipStreamWaitEvent(h->stream, h->hp_ev[q], 0)); }      // (the switch: experiment builds, tools/stamps_forward.py)
     return BN_OK;
 }
@@ -1695,7 +1712,7 @@ static int forward_impl(bn_mppi_t *h, const float *states_device, const float *s
     if (paced && h->hp_armed && !h->hp_skip_check &&
         (hp_gave_up(h, h->hp_tag) || std::chrono::steady_clock::now() - h->hp_armed_at > std::chrono::milliseconds(20))) hp_cancel(h);
     if (paced && h->hp_armed) {                        // the loop's steady state: the launch is there and waits for exactly this
-        BN_BIND(h);
+        BN_BIND_Q(h);
         if (int rc = self_check(h)) return rc;
         const int q_posted = h->hp_q;
         if (int rc = hp_post(h, state_host, out_device)) return rc;
@@ -2423,6 +2440,13 @@ int bn_mppi_sync(bn_mppi_t *h)
     return self_check(h);
 }
 
+int bn_mppi_order_outputs(bn_mppi_t *h)
+{
+    if (!h) return fail(BN_ERR_INVALID, "null handle");
+    BN_BIND(h);                                         // (that is the call: see hp_order_now)
+    return BN_OK;
+}
+
 uint64_t bn_mppi_recovery_count(const bn_mppi_t *h) { return h ? h->recoveries : 0; }
 
 int32_t bn_mppi_overlap_mode(const bn_mppi_t *h)
@@ -2447,7 +2471,7 @@ int bn_mppi_first_action(bn_mppi_t *h, int32_t instance, float action_host[2])
     if (!action_host) return fail(BN_ERR_INVALID, "null output");
     if (h->solves == 0) return fail(BN_ERR_STATE, "no solve has run");
     if (h->shard_pending) return fail(BN_ERR_STATE, "a sharded solve waits for bn_mppi_shard_finish_async");
-    BN_BIND(h);
+    BN_BIND_Q(h);                                           // (the mailbox lives on the host: nothing of the handle's stream is touched, nothing to order)
     if (int rc = flush_tail(h)) return rc;                  // the tail is what posts it
     // The tail writes U*[0] to pinned host memory as soon as its merge is done -- two {value, tag} granules, tag = solve index + 1
     // -- and goes on with X* and the weights; the host polls the granules: no stream synchronisation, no copy.

@@ -114,6 +114,10 @@ class MPPI(nn.Module):
                       that waits is cancelled by any other library call of the planner (`release()` is the cheapest) and gives up by itself
                       after ~50 ms (the next forward() then starts over with an ordinary launch); a device-wide
                       `torch.cuda.synchronize()` issued while it waits blocks that long -- call `release()` first.
+                      host_loop="actions": for a loop that consumes `first_action()` and only now and then anything else -- forward()
+                      leaves torch's stream unordered behind the solve (that stream-wait is 3-5 us of every control step's host time);
+                      the planner's own attributes and methods (`_weights`, `_state_seq_batch`, `get_top_samples` ...) make up for it
+                      when they are read, the tensors forward() RETURNED are valid for torch work enqueued after `order_outputs()`.
       reference_order the transit in the reference's own operation order (robot_model.py:86-88: sin / cos of every step's
                       heading, x + ((trav v) cos) dt): no cell flips against the reference beyond what libm vs SLEEF gives
                       (DESIGN.md 5), on the same kernels (one launch per solve) at ~1.4x the single-instance latency -- the chain's extra
@@ -129,7 +133,7 @@ class MPPI(nn.Module):
                  sigmas: torch.Tensor, lambda_: float, device=torch.device("cuda"), dtype=torch.float32,
                  seed: int = 42, *, noise: str = "torch_device", store_controls: bool = True,
                  copy_outputs: bool = True, profile: bool = False, delta_t: float = 0.1, sampled_slip: bool = False,
-                 lean: bool = False, reference_order: bool = False, host_loop: bool = False) -> None:
+                 lean: bool = False, reference_order: bool = False, host_loop=False) -> None:
         super().__init__()
         torch.manual_seed(seed)                                    # mppi.py:55
 
@@ -189,7 +193,8 @@ class MPPI(nn.Module):
         cfg.flags = ((_capi.BN_FLAG_STORE_CONTROLS if store_controls else 0) | (_capi.BN_FLAG_PROFILE if profile else 0)
                      | (_capi.BN_FLAG_SAMPLED_SLIP if sampled_slip else 0) | (_capi.BN_FLAG_LEAN if lean else 0)
                      | (_capi.BN_FLAG_REFERENCE_ORDER if reference_order else 0)
-                     | (_capi.BN_FLAG_HOST_PACED if (host_loop and noise == "philox") else 0))
+                     | (_capi.BN_FLAG_HOST_PACED if (host_loop and noise == "philox") else 0)
+                     | (_capi.BN_FLAG_UNORDERED_OUTPUTS if (host_loop == "actions" and noise == "philox") else 0))
         self._lean = bool(lean)
         with torch.cuda.device(dev):
             self._stream = torch.cuda.current_stream(dev)
@@ -212,6 +217,7 @@ class MPPI(nn.Module):
         Kp = int(lib.bn_mppi_row_pitch(self._handle))        # rows are pitched to 64*ceil(K/64) floats
         self._buf_X = None if lean else self._wrap(_capi.BN_BUF_STATES, (T + 1, 3, Kp))[:, :, :K]
         self._host_loop = int(lib.bn_mppi_host_paced(self._handle)) >= 1
+        self._unordered = self._host_loop and host_loop == "actions"
         # host-paced solves alternate between two trajectory / control buffers (two launches in flight): bn_mppi_states_buffer_index
         self.__dict__["_buf_X_alt"] = self._wrap(_capi.BN_BUF_STATES_ALT, (T + 1, 3, Kp))[:, :, :K] if (self._host_loop and not lean) else None
         self._buf_w = self._wrap(_capi.BN_BUF_WEIGHTS, (K,))
@@ -279,6 +285,7 @@ class MPPI(nn.Module):
     # -- reference attributes --------------------------------------------------------
     @property
     def _previous_action_seq(self) -> torch.Tensor:
+        self._unordered and self.order_outputs()
         return self._buf_mean
 
     @_previous_action_seq.setter
@@ -290,6 +297,7 @@ class MPPI(nn.Module):
     def _state_seq_batch(self) -> torch.Tensor:
         """(K, T+1, 3): a view of the planner-native (T+1, 3, K) buffer (no copy); in lean mode the rows are re-rolled
         on first access after a forward() (bit-identical to what a full-API solve stores)."""
+        self._unordered and self.order_outputs()
         if self._lean:
             if self._cs.rolled is None:
                 self._cs.rolled = self._reroll(None, self._num_samples)
@@ -297,6 +305,11 @@ class MPPI(nn.Module):
         if self._host_loop and self._lib.bn_mppi_states_buffer_index(self._h) == 1:
             return self._buf_X_alt.permute(2, 0, 1)
         return self._buf_X.permute(2, 0, 1)
+
+    def order_outputs(self) -> None:
+        """host_loop="actions": order torch's stream behind the latest solve -- before torch work that consumes the tensors forward()
+        returned.  A no-op otherwise; the loop keeps its pace (the launch that waits for the next state is left alone)."""
+        _capi.check(self._lib.bn_mppi_order_outputs(self._handle))
 
     def release(self) -> None:
         """End a `host_loop` loop: cancels the launch that waits on the device for the next state (a word in pinned memory, no
@@ -311,16 +324,19 @@ class MPPI(nn.Module):
 
     @property
     def _weights(self) -> torch.Tensor:
+        self._unordered and self.order_outputs()
         return self._buf_w
 
     @property
     def _costs(self) -> torch.Tensor:
+        self._unordered and self.order_outputs()
         return self._buf_cost
 
     @property
     def _perturbed_action_seqs(self) -> torch.Tensor:
         if self._buf_U is None:
             raise AttributeError("_perturbed_action_seqs is not stored (store_controls=False)")
+        self._unordered and self.order_outputs()
         if self._host_loop and self._lib.bn_mppi_states_buffer_index(self._h) == 1:
             return self._buf_U_alt.permute(2, 0, 1)
         return self._buf_U.permute(2, 0, 1)

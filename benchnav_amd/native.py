@@ -32,7 +32,7 @@ class NativeMPPI:
                  dt: float = 0.1, stuck_threshold: float = 0.3, num_instances: int = 1, shared_map: bool = False,
                  seed: int = 42, device_id: int = 0, store_controls: bool = False, lds_window: bool = True,
                  profile: bool = False, stream: Optional[int] = None, pipeline: bool = True, sampled_slip: bool = False, kernel: str = "auto",
-                 lean: bool = False, overlap: bool = True, reference_order: bool = False, host_paced: bool = False):
+                 lean: bool = False, overlap: bool = True, reference_order: bool = False, host_paced: bool = False, unordered_outputs: bool = False):
         self._lib = _capi.load()
         self._h = C.c_void_p()
         cfg = _capi.Config()
@@ -64,6 +64,7 @@ class NativeMPPI:
                      | (0 if overlap else _capi.BN_FLAG_NO_OVERLAP)
                      | (_capi.BN_FLAG_REFERENCE_ORDER if reference_order else 0)
                      | (_capi.BN_FLAG_HOST_PACED if host_paced else 0)
+                     | (_capi.BN_FLAG_UNORDERED_OUTPUTS if unordered_outputs else 0)
                      | {"auto": 0, "wave": _capi.BN_FLAG_WAVE_KERNEL, "role": _capi.BN_FLAG_ROLE_KERNEL, "lat": _capi.BN_FLAG_LAT_KERNEL}[kernel])
         cfg.stream = stream        # an int hipStream_t; 0 is the null stream (torch's default); None = private stream
         self.K, self.T, self.G, self.B = num_samples, horizon, grid_size, num_instances
@@ -163,6 +164,10 @@ class NativeMPPI:
     def host_paced(self) -> bool:
         """BN_FLAG_HOST_PACED was given and the handle qualifies: forward_state_async enqueues the next solve's launch one step ahead."""
         return int(self._lib.bn_mppi_host_paced(self._h)) >= 1
+
+    def order_outputs(self) -> None:
+        """BN_FLAG_UNORDERED_OUTPUTS: order the handle's stream behind the latest posted solve (before the caller's own consumers)."""
+        _capi.check(self._lib.bn_mppi_order_outputs(self._h))
 
     def states_buffer_index(self) -> int:
         return int(self._lib.bn_mppi_states_buffer_index(self._h))

@@ -91,6 +91,11 @@ enum {
                                           first action (test_mppi.py:174-181): the launch of the NEXT solve is enqueued one step ahead and waits on
                                           the device for the state the next call posts -- see bn_mppi_forward_state_async.  One instance, latency
                                           kernel, num_samples <= 1024, Philox noise; bn_mppi_host_paced() tells whether the handle qualifies */
+    BN_FLAG_UNORDERED_OUTPUTS = 1u << 14, /* with BN_FLAG_HOST_PACED, for a loop that consumes the first action and rarely anything else: the steady-state
+                                          bn_mppi_forward_state_async does NOT order the handle's stream behind the posted solve (3-5 us of host
+                                          time per control step).  Every other entry point of the handle (bn_mppi_first_action and the pure queries
+                                          aside) makes up for it when it is called; a caller that enqueues its OWN consumers of `out_device` or of
+                                          the device buffers calls bn_mppi_order_outputs first */
     BN_FLAG_REFERENCE_ORDER = 1u << 12 /* the transit in the REFERENCE's own operation order, robot_model.py:75-95: sin / cos of every
                                           step's heading, x + ((trav v) cos) dt, theta + (trav omega) dt, the general heading wrap.
                                           The default arithmetic (heading vector carried by a rotation per step, one fused update) leaves
@@ -214,7 +219,7 @@ int bn_mppi_forward_state_async(bn_mppi_t *h, const float *states_host, const fl
  * the cost epilogue and the merge are left: 25 -> ~14 us per control step at K = 1024, T = 50.  Results are bit-identical to the
  * one-launch path's (same noise stream positions, same merges).
  *   - outputs stay stream-ordered for what comes AFTER: every posted solve's launch is followed by an event the handle's stream waits
- *     for.  What was enqueued on the handle's stream BEFORE the call is not waited for (the launch is paced by the host's store, not by
+ *     for (BN_FLAG_UNORDERED_OUTPUTS: not before the next call that needs it, see bn_mppi_order_outputs).  What was enqueued on the handle's stream BEFORE the call is not waited for (the launch is paced by the host's store, not by
  *     the queue): work left there that still reads the planner's own buffers (BN_BUF_WEIGHTS, BN_BUF_STATES, BN_BUF_USTAR_XSTAR ...),
  *     or that still uses the memory `out_device` was carved from, must have completed -- fresh output blocks per call need nothing;
  *   - a launch that waits for a state holds 17 CUs and is cancelled -- a word in pinned memory, no synchronisation -- by every other
@@ -224,6 +229,9 @@ int bn_mppi_forward_state_async(bn_mppi_t *h, const float *states_host, const fl
  *     those 50 ms: end the loop with any other call of the handle (bn_mppi_flush is the cheapest) first.  This is why the mode is
  *     opt-in;
  *   - a state more than two cells from the previous one (a reset) is handled inside the waiting launch (it stages its window again). */
+/* BN_FLAG_UNORDERED_OUTPUTS: order the handle's stream behind the latest posted solve (one stream-wait; a no-op when that has been done
+ * or the flag is not set).  Does not cancel the launch that waits for the next state: the loop keeps its pace. */
+int bn_mppi_order_outputs(bn_mppi_t *h);
 int32_t bn_mppi_host_paced(const bn_mppi_t *h);      /* 0: no; 1: BN_FLAG_HOST_PACED was given and the handle qualifies; 2: ... and the request words live in
                                                          device memory the host writes through the PCIe BAR (no PCIe read on the launch's side) */
 /* Which of the two trajectory / control buffers holds the LATEST solve (0: BN_BUF_STATES / BN_BUF_CONTROLS, 1: the *_ALT ones): host-paced

@@ -44,6 +44,7 @@ def test_the_line_carries_the_reference_boundarys_own_figure():
     assert d["launches_per_forward"] == 1 and d["host_loop"] is True and d["first_action_equals_action_seq0"] is True
     assert d["value"] > 35000 and d["us_per_step"] < d["without_host_loop"]["us_per_step"] < d["with_cpu_readback"]["us_per_step"] + 10
     assert abs(sum(d["split_us"].values()) - d["us_per_step"]) < 0.5
+    assert d["host_loop_actions"]["first_action_equals_action_seq0"] is True and d["host_loop_actions"]["us_per_step"] < d["without_host_loop"]["us_per_step"]
 
 
 def test_gpus_2_self_launches_two_ranks_on_the_device():

@@ -143,14 +143,18 @@ def test_drop_in_class_host_loop():
     from helpers import load_case, mppi_for_fixture
     fx = load_case("c2")
     outs = {}
-    for loop in (True, False):
+    for loop in (True, "actions", False):
         solver = mppi_for_fixture(fx, noise="philox", store_controls=True, host_loop=loop)
-        assert solver._host_loop == loop
+        assert solver._host_loop == bool(loop) and solver._unordered == (loop == "actions")
         state = torch.tensor(fx["state_0"])
         seq = []
         for i in range(9):
             U, X = solver(state)
             a = solver.first_action().clone()
+            if i % 2:
+                solver.order_outputs()                   # "actions": what forward() returned is ordered from here (a no-op otherwise) ...
+            else:
+                solver._weights                          # ... and so it is behind any of the planner's own attributes
             seq.append((U.clone(), X.clone(), a, solver._weights.clone(), solver._state_seq_batch[::37].clone(), solver._perturbed_action_seqs[::41].clone()))
             if i == 4:
                 seq.append(tuple(t.clone() for t in solver.get_top_samples(7)))
@@ -159,9 +163,47 @@ def test_drop_in_class_host_loop():
         torch.cuda.synchronize()
         outs[loop] = [tuple(t.cpu().numpy() for t in rec) for rec in seq]
         assert np.array_equal(outs[loop][0][2], outs[loop][0][0][0])
-    for i, (ra, rb) in enumerate(zip(outs[True], outs[False])):
-        for j, (a, b) in enumerate(zip(ra, rb)):
-            assert np.array_equal(a, b), (i, j)
+    for loop in (True, "actions"):
+        for i, (ra, rb) in enumerate(zip(outs[loop], outs[False])):
+            for j, (a, b) in enumerate(zip(ra, rb)):
+                assert np.array_equal(a, b), (loop, i, j)
+
+
+def test_unordered_outputs_are_ordered_by_the_first_call_that_needs_them():
+    """BN_FLAG_UNORDERED_OUTPUTS: the steady-state forward leaves the handle's stream alone; bn_mppi_order_outputs, or any entry point that
+    enqueues on the stream or hands out results, orders it behind the latest posted solve.  Copies taken on the stream right behind such a
+    call, in the middle of the loop, hold the finished block; the loop's results are those of the one-launch loop."""
+    import torch
+    from benchnav_amd import synth
+    K, T, G = 1024, 50, 256
+    inst = synth.make_instance(G, seed=11)
+    states = _states(inst, 16, jump_at=(9,))
+    n_out = T * 2 + (T + 1) * 3
+    res = {}
+    for paced in (True, False):
+        with _planner(K, T, G, inst, paced, unordered_outputs=paced) as pl:
+            assert pl.host_paced() == paced
+            copies, acts, blocks = [], [], []
+            for i, st in enumerate(states):
+                o = torch.full((n_out,), float("nan"), device="cuda")
+                torch.cuda.current_stream().synchronize()
+                pl.forward_state_async(st, None, 0, o.data_ptr())
+                acts.append(pl.first_action().copy())
+                blocks.append(o)
+                if i % 3 == 0:
+                    pl.order_outputs()
+                    copies.append(o.clone())                 # on the handle's stream (stream=0), right behind the ordering call
+                elif i % 3 == 1:
+                    w = pl.weights()                         # a getter: orders (and cancels the waiting launch)
+                    copies.append(o.clone())
+                    copies.append(torch.from_numpy(w))
+            pl.flush(); torch.cuda.synchronize(); pl.sync()
+            res[paced] = ([c.cpu().numpy() for c in copies], acts, [b.cpu().numpy() for b in blocks], (pl.states(), pl.costs(), pl.weights(), pl.get_mean()))
+    for k in range(4):
+        assert len(res[True][k]) == len(res[False][k])
+        for i, (a, b) in enumerate(zip(res[True][k], res[False][k])):
+            assert np.array_equal(a, b), (k, i)
+    assert all(np.isfinite(c).all() for c in res[True][0])
 
 
 def test_forwards_fired_back_to_back_are_held_to_the_devices_pace():

@@ -9,12 +9,12 @@ torch.set_num_threads(1)
 fx = load_case("c2")
 import sys as _sys
 quick = "--quick" in _sys.argv
-combos = ((("philox", True, False, "cpu"), ("philox", True, False, "loop"), ("philox", False, False, "loop")) if quick else
+combos = ((("philox", True, False, "cpu"), ("philox", True, False, "loop"), ("philox", True, False, "acts")) if quick else
           (("torch", True, False, "cuda"), ("torch_device", True, False, "cuda"), ("philox", True, False, "cuda"), ("philox", True, False, "cpu"),
            ("philox", False, False, "cuda"), ("philox", False, False, "cpu"), ("philox", False, True, "cpu"), ("philox", True, False, "loop"), ("philox", False, False, "loop")))
 for mode, copy, lean, where in combos:
-    solver = mppi_for_fixture(fx, noise=mode, copy_outputs=copy, store_controls=False, lean=lean, host_loop=(where == "loop"))      # "loop": MPPI(host_loop=True), CPU state
-    state = torch.tensor(fx["state_0"], device="cpu" if where == "loop" else where)      # "cpu": the host loop's state, taken by value (bn_mppi_forward_state_async)
+    solver = mppi_for_fixture(fx, noise=mode, copy_outputs=copy, store_controls=False, lean=lean, host_loop=({"loop": True, "acts": "actions"}.get(where, False)))      # "loop": MPPI(host_loop=True), CPU state
+    state = torch.tensor(fx["state_0"], device="cpu" if where in ("loop", "acts") else where)      # "cpu": the host loop's state, taken by value (bn_mppi_forward_state_async)
     for _ in range(50): U, X = solver(state)
     solver.release(); torch.cuda.synchronize(); n = 500
     host = 0.0
@@ -23,6 +23,7 @@ for mode, copy, lean, where in combos:
         t0 = time.perf_counter()
         U, X = solver(state)
         host += time.perf_counter() - t0
+        solver.order_outputs()              # (host_loop="actions": the read-back needs the stream ordered; a no-op otherwise)
         a = U[0].cpu()                      # the reference loop reads action_seq[0] every step
     dt = (time.perf_counter() - t) / n
     solver.release()
