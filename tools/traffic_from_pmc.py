@@ -24,7 +24,7 @@ for case, key in KEYS.items():
     wk, kw, nw = dominant(w, "WRITE_SIZE")
     out[key] = int(round((2 * fk + wk) * 1024))
     detail[case] = {"fetch_KiB_counter": fk, "fetch_KiB_corrected": 2 * fk, "write_KiB": wk, "kernel": kf, "dispatches": [nf, nw]}
-out["collected"] = f"profiles/{tag}_pmc/*_fetch.csv + *_write.csv at commit {commit}: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch, one bench leg per rocprofv3 --pmc pass (tools/profile_round5.sh)"
+out["collected"] = f"profiles/{tag}_pmc/*_fetch.csv + *_write.csv at commit {commit}: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 per launch, one bench leg per rocprofv3 --pmc pass (tools/profile_round6.sh)"
 out["source"] = out["collected"]
 out["detail"] = detail
 json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
