@@ -684,7 +684,7 @@ def dropin_forward(inst, dev, n_steps):
             U, X = solver.forward(state)
             tb = time.perf_counter()
             act = U[0].cpu() if readback else solver.first_action()
-            a0, a1 = float(act[0]), float(act[1])
+            a0, a1 = act.tolist()                        # (one call: two tensor indexings cost more than the environment step)
             tc = time.perf_counter()
             env_step(a0, a1)
             td = time.perf_counter()
